@@ -1,0 +1,116 @@
+"""Layer factory + graph preprocessing, without DGL.
+
+Same function names, return tuples and `--format` dispatch as the reference's DFGNN/layers/util.py
+(:52-57 g_to_SPmatrix, :66-100 preprocess_CSR/Hyper, :116-142 preprocess_Hyper_fw_bw,
+:145-162 preprocess_softmax, :362-491 load_*).  COO -> CSR/CSC is done with torch sorts on whatever
+device the graph lives on; index arrays come out int32, values fp32 (all ones, like
+`dglsp.spmatrix`'s default).
+
+`smem_consume` keeps the reference's formula (128 neighbours/row guess) purely for signature
+compatibility: the kernels size LDS per workgroup themselves and never overflow.
+"""
+import torch
+
+from DFGNN.utils import sparse as dglsp
+
+from .GAT import GATConv_dgNN, GATConv_hyper, GATConv_softmax, GATConv_softmax_gm, GATConv_tiling
+from .GT import (SparseMHA_CSR, SparseMHA_CSR_GM, SparseMHA_forward_timing, SparseMHA_hyper, SparseMHA_softmax,
+                 SparseMHA_softmax_gm, SparseMHA_tiling)
+
+WARP_SIZE = 32  # only used by the smem_consume formula kept from the reference
+
+
+def g_to_SPmatrix(g):
+    indices = torch.stack(g.edges())
+    N = g.num_nodes()
+    return dglsp.spmatrix(indices, shape=(N, N)), 128
+
+
+def _round_up(x, to):
+    return (x + to - 1) // to * to
+
+
+def _csr_parts(A):
+    row_ptr, col_ind, val_idx = A.csr()
+    return row_ptr.int(), col_ind.int(), A.val[val_idx]
+
+
+def preprocess_CSR(g, **args):
+    A, max_neigh = g_to_SPmatrix(g)
+    row_ptr, col_ind, val = _csr_parts(A)
+    return row_ptr, col_ind, val, _round_up(max_neigh, WARP_SIZE)
+
+
+def preprocess_Hyper(g, **args):
+    A, max_neigh = g_to_SPmatrix(g)
+    rows = torch.sort(A.row.int()).values
+    row_ptr, col_ind, val = _csr_parts(A)
+    return row_ptr, col_ind, rows, val, _round_up(max_neigh * 8, WARP_SIZE)
+
+
+def preprocess_softmax(g, **args):
+    A, max_neigh = g_to_SPmatrix(g)
+    rows = torch.sort(A.row.int()).values
+    row_ptr, col_ind, val = _csr_parts(A)
+    return row_ptr, col_ind, rows, val, _round_up(max_neigh, WARP_SIZE)
+
+
+def preprocess_Hyper_fw_bw(g, fused=True):
+    A, max_neigh = g_to_SPmatrix(g)
+    if not fused:
+        return A, None, None, None, None, None, None, None, None
+    rows = torch.sort(A.row.int()).values
+    row_ptr, col_ind, val = _csr_parts(A)
+    A_csr = dglsp.from_csr(indptr=row_ptr, indices=col_ind, val=val, shape=A.shape)
+    col_ptr, row_ind, val_idx = A_csr.csc()
+    return (A, rows, row_ptr, col_ind, val, col_ptr.int(), row_ind.int(), val_idx.int(),
+            _round_up(max_neigh * 8, WARP_SIZE))
+
+
+_GT_LAYERS = {
+    "csr": SparseMHA_CSR, "csr_gm": SparseMHA_CSR_GM, "tiling": SparseMHA_tiling, "hyper": SparseMHA_hyper,
+    "nofuse": SparseMHA_hyper, "softmax": SparseMHA_softmax, "softmax_gm": SparseMHA_softmax_gm,
+    "forward": SparseMHA_forward_timing,
+}
+_GAT_LAYERS = {
+    "csr": GATConv_dgNN, "tiling": GATConv_tiling, "hyper": GATConv_hyper, "nofuse": GATConv_hyper,
+    "softmax": GATConv_softmax, "softmax_gm": GATConv_softmax_gm,
+}
+# formats of the reference that are baselines on NVIDIA-only libraries or paper experiments
+_OUT_OF_SCOPE = {"hybrid", "hyper_ablation", "pyg", "cugraph", "hyper_v2", "hyper_recompute", "subgraph"}
+
+
+def _pick(table, args, conv):
+    if args.format in table:
+        return table[args.format](args.dim, args.dim, args.heads)
+    if args.format in _OUT_OF_SCOPE:
+        raise ValueError(f"format {args.format} for {conv} is outside this build's scope (SURVEY.md 2.1)")
+    raise ValueError(f"Unsupported format {args.format} in {conv}")
+
+
+def load_layer_GT(args):
+    return _pick(_GT_LAYERS, args, "GTconv")
+
+
+def load_layer_GAT(args):
+    return _pick(_GAT_LAYERS, args, "GATconv")
+
+
+def load_graphconv_layer(args):
+    if args.conv == "gat":
+        return load_layer_GAT(args)
+    if args.conv == "gt":
+        return load_layer_GT(args)
+    raise ValueError(f"unknown graph conv {args.conv}")
+
+
+def load_prepfunc(args):
+    if args.format in ("csr", "csr_gm", "tiling"):
+        return preprocess_CSR
+    if args.format in ("hyper", "nofuse"):
+        return preprocess_Hyper
+    if args.format in ("softmax", "softmax_gm"):
+        return preprocess_softmax
+    if args.format == "forward":
+        return preprocess_Hyper_fw_bw
+    raise ValueError(f"Unsupported format {args.format}")

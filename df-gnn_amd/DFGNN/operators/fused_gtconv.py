@@ -1,0 +1,71 @@
+"""GT operator surface -- same names / signatures as the reference's DFGNN/operators/fused_gtconv.py.
+
+Each function forwards to the `fused_gtconv` binding module (MI355X HIP kernels behind the C ABI).
+Return conventions follow the reference: the binding returns a list for most entry points and the
+wrapper unwraps element 0; `softmax_gm` returns a bare tensor (reference :279).
+Note the argument-order quirk kept from the reference: `GTConvFuse_hyper` takes `rows` first, the
+binding takes `row_ptr` first (reference :51-107).
+"""
+import fused_gtconv as fused_gt
+import torch
+
+
+def GTConvFuse_inference_hyper(indptr, indices, rows, val, smem_consume, Q, K, V):
+    """hyper: one kernel, CSR + COO.  reference :5-25"""
+    return fused_gt.gt_hyper_inference(indptr, indices, rows, val, smem_consume, Q, K, V)[0]
+
+
+def GTConvFuse_inference_hyper_ablation(indptr, indices, rows, val, smem_consume, Q, K, V):
+    """reference :28-48"""
+    return fused_gt.gt_hyper_inference_ablation(indptr, indices, rows, val, smem_consume, Q, K, V)[0]
+
+
+class FusedGTFunction_hyper(torch.autograd.Function):
+    """Fused forward (saves the normalised attention) + fused backward.  reference :79-158"""
+
+    @staticmethod
+    def forward(ctx, rows, row_ptr, col_ind, val, col_ptr, row_ind, val_idx, smem_consume, Q, K, V):
+        out_feat, attn_edge = fused_gt.gt_hyper_forward(
+            row_ptr, col_ind, rows, val, col_ptr, row_ind, val_idx, smem_consume, Q, K, V)
+        ctx.smem = smem_consume
+        ctx.save_for_backward(row_ptr, col_ind, rows, val, col_ptr, row_ind, val_idx, Q, K, V, attn_edge)
+        return out_feat
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        row_ptr, col_ind, rows, val, col_ptr, row_ind, val_idx, Q, K, V, attn_edge = ctx.saved_tensors
+        grad_Q, grad_K, grad_V = fused_gt.gt_backward(
+            row_ptr, col_ind, rows, val, col_ptr, row_ind, val_idx, ctx.smem, Q, K, V, attn_edge,
+            grad_out.contiguous())
+        return (None,) * 8 + (grad_Q, grad_K, grad_V)
+
+
+def GTConvFuse_hyper(rows, row_ptr, col_ind, val, col_ptr, row_ind, val_idx, smem_consume, Q, K, V):
+    """Differentiable hyper conv.  reference :51-76"""
+    return FusedGTFunction_hyper.apply(
+        rows, row_ptr, col_ind, val, col_ptr, row_ind, val_idx, smem_consume, Q, K, V)
+
+
+def GTConvFuse_inference_softmax(indptr, indices, rows, val, smem_consume, Q, K, V):
+    """softmax: two kernels (COO SDDMM, then softmax + SpMM).  reference :238-259"""
+    return fused_gt.gt_softmax_inference(indptr, indices, rows, val, smem_consume, Q, K, V)[0]
+
+
+def GTConvFuse_inference_softmax_gm(indptr, indices, rows, val, Q, K, V):
+    """softmax with logits kept in global memory; bare tensor.  reference :262-279"""
+    return fused_gt.gt_softmax_gm_inference(indptr, indices, rows, val, Q, K, V)
+
+
+def GTConvFuse_inference_csr(indptr, indices, val, smem_consume, Q, K, V):
+    """reference :282-301"""
+    return fused_gt.gt_csr_inference(indptr, indices, val, smem_consume, Q, K, V)[0]
+
+
+def GTConvFuse_inference_csr_gm(indptr, indices, val, Q, K, V):
+    """reference :304-321"""
+    return fused_gt.gt_csr_gm_inference(indptr, indices, val, Q, K, V)[0]
+
+
+def GTConvFuse_inference_tiling(indptr, indices, val, smem_consume, Q, K, V):
+    """tiling: one kernel, column tiles + online softmax.  reference :324-343"""
+    return fused_gt.gt_tiling_inference(indptr, indices, val, smem_consume, Q, K, V)[0]

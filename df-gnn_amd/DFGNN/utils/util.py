@@ -1,0 +1,141 @@
+"""Harness helpers with the reference's names and behaviour (DFGNN/utils/util.py).
+
+  benchmark / Timer    3 dry runs + 10 timed calls between device events      (reference :368-400)
+  check_correct        row-wise isclose(rtol=1e-3) report, no assertion       (reference :211-236)
+  parser_argument      the reference's CLI flags + optional YAML              (reference :403-446)
+  preprocess_dglsp     edge list -> sparse matrix for the non-fused branch    (reference :239-243)
+  inference_*_level    the per-batch nofuse/fuse loop                         (reference :246-322)
+Dataset loaders are not mirrored (they are commented out in the reference snapshot and need
+network datasets): DFGNN.utils.synthetic provides same-shaped synthetic graphs instead.
+"""
+from timeit import default_timer
+
+import torch
+import yaml
+
+from . import sparse as dglsp
+
+datasets_NC = ["PascalVOC-SP", "COCO-SP", "PATTERN", "CLUSTER"]
+
+
+class Timer:
+    """Event-based timer on the current device; wall clock when no GPU is present
+    (the reference hard-codes "cuda:0", :371)."""
+
+    def __init__(self):
+        self.timer = default_timer
+        self.device = "cuda" if torch.cuda.is_available() else "cpu"
+
+    def __enter__(self):
+        if self.device == "cuda":
+            self.start_event = torch.cuda.Event(enable_timing=True)
+            self.end_event = torch.cuda.Event(enable_timing=True)
+            self.start_event.record()
+        else:
+            self.tic = self.timer()
+        return self
+
+    def __exit__(self, exc_type, exc, tb):
+        if self.device == "cuda":
+            self.end_event.record()
+            torch.cuda.synchronize()
+            self.elapsed_secs = self.start_event.elapsed_time(self.end_event) / 1e3
+        else:
+            self.elapsed_secs = self.timer() - self.tic
+
+
+def benchmark(function, *args):
+    for _ in range(3):
+        out = function(*args)
+    with Timer() as t:
+        for _ in range(10):
+            out = function(*args)
+    return out, t.elapsed_secs / 10
+
+
+def check_correct(logits, logits_fuse, params=None):
+    """Prints the reference's verdict line; additionally returns True/False so tests can assert."""
+    close = torch.isclose(logits, logits_fuse, rtol=0.001)
+    rows_ok = close.reshape(close.shape[0], -1).all(dim=1) if close.dim() > 1 else close
+    if bool(rows_ok.all()):
+        print("the results are the same, success!!!!!!!!!!")
+        return True
+    bad = int(torch.argwhere(~rows_ok)[0])
+    # the reference tolerates a single mismatching element per row (:226)
+    row_close = close[bad].reshape(-1)
+    if int(row_close.sum()) + 1 != row_close.numel():
+        print(f"error node {bad} mismatch")
+        print("nonfuse result", logits[bad])
+        print("fuse result", logits_fuse[bad])
+        return False
+    print("the results are the same, success!!!!!!!!!!")
+    return True
+
+
+def preprocess_dglsp(g, **args):
+    indices = torch.stack(g.edges())
+    N = g.num_nodes()
+    return dglsp.spmatrix(indices, shape=(N, N))
+
+
+def _inference(process_func, model, dataloader, dev, graph_level):
+    print("----------------------Forward------------------------")
+    time_no_fuse, time_fuse, warmup = [], [], 1
+    for i, item in enumerate(dataloader):
+        batched_g = (item[0] if graph_level else item).to(dev)
+        params = preprocess_dglsp(batched_g)
+        model.eval()
+        logits, elapsed = model(params, batched_g.ndata["feat"])
+        print(f"epoch {i} non-fused time %.4f" % elapsed)
+        if i >= warmup:
+            time_no_fuse.append(elapsed)
+            params = process_func(batched_g)
+            logits_fuse, elapsed = model(params, batched_g.ndata["feat"], fuse=True)
+            time_fuse.append(elapsed)
+            print(f"epoch {i} fused time %.4f" % elapsed)
+            if i < 3:
+                check_correct(logits[:1000], logits_fuse[:1000], params)
+                check_correct(logits[-1000:], logits_fuse[-1000:], params)
+            if i == 20:
+                break
+    return time_no_fuse, time_fuse
+
+
+def inference_Graph_level(process_func, model, train_dataloader, dev):
+    return _inference(process_func, model, train_dataloader, dev, True)
+
+
+def inference_Node_level(process_func, model, train_dataloader, dev):
+    return _inference(process_func, model, train_dataloader, dev, False)
+
+
+def parse_args(parser):
+    args = parser.parse_args()
+    if args.config:
+        with open(args.config, "r") as fh:
+            data = yaml.safe_load(fh)
+        delattr(args, "config")
+        d = args.__dict__
+        for key, value in data.items():
+            if key not in d or d[key] is None:
+                d[key] = value
+    return args
+
+
+def parser_argument(parser):
+    parser.add_argument("--config", type=str)
+    parser.add_argument("--conv", type=str, default="gt")
+    parser.add_argument("--format", type=str, default="all")
+    parser.add_argument("--dim", type=int)
+    parser.add_argument("--heads", type=int, default=1)
+    parser.add_argument("--batch-size", type=int)
+    parser.add_argument("--data-dir", type=str, default="./data/OGB")
+    parser.add_argument("--dataset", type=str, default="ogbg-molhiv")
+    parser.add_argument("--store-result", action="store_true")
+    parser.add_argument("--subgraph-filter", action="store_true")
+    parser.add_argument("--profile", action="store_true")
+    args = parse_args(parser)
+    for label, v in (("GraphConv", args.conv), ("Dataset", args.dataset), ("format", args.format),
+                     ("hidden dim", args.dim), ("num heads", args.heads), ("batch size", args.batch_size)):
+        print(label, v)
+    return args

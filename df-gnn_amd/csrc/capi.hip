@@ -1,0 +1,150 @@
+// capi.hip -- the extern "C" boundary of libdfgnn.so (declared in include/dfgnn.h).
+// Argument validation + dispatch only; no allocation, no synchronisation.
+#include "../../include/dfgnn.h"
+#include "dfgnn_launch.hpp"
+
+using namespace dfgnn;
+
+namespace {
+inline hipStream_t as_stream(dfgnn_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+// Returns <0 on a bad argument, 1 when there is nothing to do, 0 to proceed.
+inline int check_common(int m, int nnz, int h, int f, const void *row_ptr, const void *col_ind) {
+  if (m < 0 || nnz < 0 || h < 0 || f < 0) return kErrBadArg;
+  if (m == 0 || h == 0 || f == 0) return 1;
+  if (!row_ptr) return kErrBadArg;
+  if (nnz > 0 && !col_ind) return kErrBadArg;
+  if (h > 65535) return kErrUnsupported;
+  return 0;
+}
+}  // namespace
+
+extern "C" {
+
+int dfgnn_abi_version(void) { return DFGNN_ABI_VERSION; }
+
+const char *dfgnn_error_string(int code) {
+  if (code == 0) return "success";
+  if (code == DFGNN_E_BADARG) return "dfgnn: bad argument (negative size or NULL required pointer)";
+  if (code == DFGNN_E_UNSUPPORTED)
+    return "dfgnn: unsupported shape (f > 1024, f % 4 != 0 with f > 256, or h > 65535)";
+  if (code > 0) return hipGetErrorString(static_cast<hipError_t>(code));
+  return "dfgnn: unknown error";
+}
+
+int dfgnn_gt_hyper_fwd(int m, int nnz, int h, int f, const int *row_ptr, const int *col_ind, const int *rows,
+                       const float *val, const float *Q, const float *K, const float *V, float *attn_edge,
+                       float *out, dfgnn_stream_t stream) {
+  if (int c = check_common(m, nnz, h, f, row_ptr, col_ind)) return c < 0 ? c : 0;
+  if (!Q || !K || !V || !out || (nnz > 0 && !rows)) return kErrBadArg;
+  const Csr g{m, nnz, h, f, row_ptr, col_ind, rows, val};
+  return launch_gt_hyper_fwd(g, Q, K, V, attn_edge, out, as_stream(stream));
+}
+
+int dfgnn_gt_bwd_rows(int m, int nnz, int h, int f, const int *row_ptr, const int *col_ind, const int *rows,
+                      const float *val, const float *K, const float *V, const float *attn_edge,
+                      const float *grad_out, float *grad_edge, float *dQ, dfgnn_stream_t stream) {
+  if (int c = check_common(m, nnz, h, f, row_ptr, col_ind)) return c < 0 ? c : 0;
+  if (!K || !V || !grad_out || !dQ) return kErrBadArg;
+  if (nnz > 0 && (!rows || !attn_edge || !grad_edge)) return kErrBadArg;
+  const Csr g{m, nnz, h, f, row_ptr, col_ind, rows, val};
+  return launch_gt_bwd_rows(g, K, V, attn_edge, grad_out, grad_edge, dQ, as_stream(stream));
+}
+
+int dfgnn_gt_bwd_cols(int m, int nnz, int h, int f, const float *val, const int *col_ptr, const int *row_ind,
+                      const int *val_idx, const float *Q, const float *attn_edge, const float *grad_edge,
+                      const float *grad_out, float *dK, float *dV, dfgnn_stream_t stream) {
+  if (m < 0 || nnz < 0 || h < 0 || f < 0) return kErrBadArg;
+  if (m == 0 || h == 0 || f == 0) return 0;
+  if (h > 65535) return kErrUnsupported;
+  if (!col_ptr || !Q || !grad_out || !dK || !dV) return kErrBadArg;
+  if (nnz > 0 && (!row_ind || !val_idx || !attn_edge || !grad_edge)) return kErrBadArg;
+  const Csr g{m, nnz, h, f, nullptr, nullptr, nullptr, val};
+  return launch_gt_bwd_cols(g, col_ptr, row_ind, val_idx, Q, attn_edge, grad_edge, grad_out, dK, dV,
+                            as_stream(stream));
+}
+
+int dfgnn_gt_bwd(int m, int nnz, int h, int f, const int *row_ptr, const int *col_ind, const int *rows,
+                 const float *val, const int *col_ptr, const int *row_ind, const int *val_idx, const float *Q,
+                 const float *K, const float *V, const float *attn_edge, const float *grad_out,
+                 float *grad_edge, float *dQ, float *dK, float *dV, dfgnn_stream_t stream) {
+  if (int rc = dfgnn_gt_bwd_rows(m, nnz, h, f, row_ptr, col_ind, rows, val, K, V, attn_edge, grad_out, grad_edge,
+                                 dQ, stream))
+    return rc;
+  return dfgnn_gt_bwd_cols(m, nnz, h, f, val, col_ptr, row_ind, val_idx, Q, attn_edge, grad_edge, grad_out, dK,
+                           dV, stream);
+}
+
+int dfgnn_gt_tiling_fwd(int m, int nnz, int h, int f, const int *row_ptr, const int *col_ind, const float *val,
+                        const float *Q, const float *K, const float *V, float *out, dfgnn_stream_t stream) {
+  if (int c = check_common(m, nnz, h, f, row_ptr, col_ind)) return c < 0 ? c : 0;
+  if (!Q || !K || !V || !out) return kErrBadArg;
+  const Csr g{m, nnz, h, f, row_ptr, col_ind, nullptr, val};
+  return launch_gt_tiling_fwd(g, Q, K, V, out, as_stream(stream));
+}
+
+static int gt_softmax_impl(bool use_lds, int m, int nnz, int h, int f, const int *row_ptr, const int *col_ind,
+                           const int *rows, const float *val, const float *Q, const float *K, const float *V,
+                           float *logits, float *out, dfgnn_stream_t stream) {
+  if (int c = check_common(m, nnz, h, f, row_ptr, col_ind)) return c < 0 ? c : 0;
+  if (!Q || !K || !V || !out || (nnz > 0 && (!rows || !logits))) return kErrBadArg;
+  const Csr g{m, nnz, h, f, row_ptr, col_ind, rows, val};
+  if (int rc = launch_gt_sddmm(g, Q, K, logits, as_stream(stream))) return rc;
+  return launch_softmax_spmm(g, logits, V, out, use_lds, as_stream(stream));
+}
+
+int dfgnn_gt_softmax_fwd(int m, int nnz, int h, int f, const int *row_ptr, const int *col_ind, const int *rows,
+                         const float *val, const float *Q, const float *K, const float *V, float *logits,
+                         float *out, dfgnn_stream_t stream) {
+  return gt_softmax_impl(true, m, nnz, h, f, row_ptr, col_ind, rows, val, Q, K, V, logits, out, stream);
+}
+
+int dfgnn_gt_softmax_gm_fwd(int m, int nnz, int h, int f, const int *row_ptr, const int *col_ind,
+                            const int *rows, const float *val, const float *Q, const float *K, const float *V,
+                            float *logits, float *out, dfgnn_stream_t stream) {
+  return gt_softmax_impl(false, m, nnz, h, f, row_ptr, col_ind, rows, val, Q, K, V, logits, out, stream);
+}
+
+int dfgnn_gat_hyper_fwd(int m, int nnz, int h, int f, const int *row_ptr, const int *col_ind, const int *rows,
+                        const float *attn_row, const float *attn_col, float negative_slope, const float *X,
+                        float *out, dfgnn_stream_t stream) {
+  if (int c = check_common(m, nnz, h, f, row_ptr, col_ind)) return c < 0 ? c : 0;
+  if (!attn_row || !attn_col || !X || !out || (nnz > 0 && !rows)) return kErrBadArg;
+  const Csr g{m, nnz, h, f, row_ptr, col_ind, rows, nullptr};
+  return launch_gat_hyper_fwd(g, attn_row, attn_col, negative_slope, X, out, as_stream(stream));
+}
+
+static int gat_softmax_impl(bool use_lds, int m, int nnz, int h, int f, const int *row_ptr, const int *col_ind,
+                            const int *rows, const float *attn_row, const float *attn_col, float negative_slope,
+                            const float *X, float *logits, float *out, dfgnn_stream_t stream) {
+  if (int c = check_common(m, nnz, h, f, row_ptr, col_ind)) return c < 0 ? c : 0;
+  if (!attn_row || !attn_col || !X || !out || (nnz > 0 && (!rows || !logits))) return kErrBadArg;
+  const Csr g{m, nnz, h, f, row_ptr, col_ind, rows, nullptr};
+  if (int rc = launch_gat_sddmm(g, attn_row, attn_col, negative_slope, logits, as_stream(stream))) return rc;
+  return launch_softmax_spmm(g, logits, X, out, use_lds, as_stream(stream));
+}
+
+int dfgnn_gat_softmax_fwd(int m, int nnz, int h, int f, const int *row_ptr, const int *col_ind, const int *rows,
+                          const float *attn_row, const float *attn_col, float negative_slope, const float *X,
+                          float *logits, float *out, dfgnn_stream_t stream) {
+  return gat_softmax_impl(true, m, nnz, h, f, row_ptr, col_ind, rows, attn_row, attn_col, negative_slope, X,
+                          logits, out, stream);
+}
+
+int dfgnn_gat_softmax_gm_fwd(int m, int nnz, int h, int f, const int *row_ptr, const int *col_ind,
+                             const int *rows, const float *attn_row, const float *attn_col, float negative_slope,
+                             const float *X, float *logits, float *out, dfgnn_stream_t stream) {
+  return gat_softmax_impl(false, m, nnz, h, f, row_ptr, col_ind, rows, attn_row, attn_col, negative_slope, X,
+                          logits, out, stream);
+}
+
+int dfgnn_gat_tiling_fwd(int m, int nnz, int h, int f, const int *row_ptr, const int *col_ind,
+                         const float *attn_row, const float *attn_col, float negative_slope, const float *X,
+                         float *out, dfgnn_stream_t stream) {
+  if (int c = check_common(m, nnz, h, f, row_ptr, col_ind)) return c < 0 ? c : 0;
+  if (!attn_row || !attn_col || !X || !out) return kErrBadArg;
+  const Csr g{m, nnz, h, f, row_ptr, col_ind, nullptr, nullptr};
+  return launch_gat_tiling_fwd(g, attn_row, attn_col, negative_slope, X, out, as_stream(stream));
+}
+
+}  // extern "C"

@@ -1,0 +1,191 @@
+// dfgnn_device.hpp -- wave64 building blocks shared by every kernel of libdfgnn (gfx950 only).
+//
+// Vocabulary
+//   group  : G consecutive lanes of a wave that together hold one feature row ([f] floats) as
+//            NCH chunks of VEC floats per lane.  A wave holds EPW = 64 / G rows at once, so a
+//            wave touches EPW edges per gather instruction (f = 128 -> G = 32 lanes x float4,
+//            two 512-byte rows per wave-instruction, fully coalesced).
+//   Frag   : the per-lane slice of one feature row.
+//
+// This replaces the reference's 32-lane-warp idioms (DFGNN/src/util/computeUtil.h:
+// WARP_SIZE=32, __shfl_*_sync(...,32)); nothing here is a translation of that header.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace dfgnn {
+
+constexpr int kWave = 64;
+constexpr int kBlock = 256;               // 4 waves / workgroup
+constexpr int kWavesPerBlock = kBlock / kWave;
+
+__device__ __forceinline__ float fast_exp(float x) {
+  // v_exp_f32 (2^x); relative error ~1e-7, far inside the 1e-3 parity bar.
+  return __builtin_amdgcn_exp2f(x * 1.4426950408889634f);
+}
+
+// Order this wave's LDS traffic: lanes of one wave exchange data through LDS without s_barrier
+// (DS operations of a wave execute in issue order); this only stops the compiler reordering them.
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int W>
+__device__ __forceinline__ float lanes_sum(float v) {
+#pragma unroll
+  for (int o = W / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, kWave);
+  return v;
+}
+template <int W>
+__device__ __forceinline__ float lanes_max(float v) {
+#pragma unroll
+  for (int o = W / 2; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, kWave));
+  return v;
+}
+
+template <int G_, int VEC_, int NCH_>
+struct FeatCfg {
+  static constexpr int G = G_;      // lanes per feature row
+  static constexpr int VEC = VEC_;  // floats per lane per chunk (4 -> dwordx4 loads, 1 -> dword)
+  static constexpr int NCH = NCH_;  // chunks per lane (covers f <= G*VEC*NCH)
+  static constexpr int EPW = kWave / G_;  // rows (edges) a wave holds at once
+  static_assert(G_ >= 1 && G_ <= 64 && (G_ & (G_ - 1)) == 0, "G must be a power of two <= 64");
+  static_assert(VEC_ == 1 || VEC_ == 4, "VEC is 1 or 4");
+};
+
+template <class C>
+struct Frag {
+  float v[C::NCH][C::VEC];
+};
+
+template <class C>
+__device__ __forceinline__ void frag_zero(Frag<C> &a) {
+#pragma unroll
+  for (int ch = 0; ch < C::NCH; ++ch)
+#pragma unroll
+    for (int k = 0; k < C::VEC; ++k) a.v[ch][k] = 0.f;
+}
+
+// Load this lane's slice of the feature row that starts at `base` (already offset to node+head).
+template <class C>
+__device__ __forceinline__ void frag_load(Frag<C> &a, const float *__restrict__ base, int f, int gl) {
+#pragma unroll
+  for (int ch = 0; ch < C::NCH; ++ch) {
+    const int c = (ch * C::G + gl) * C::VEC;
+    if constexpr (C::VEC == 4) {
+      if (c < f) {
+        const float4 t = *reinterpret_cast<const float4 *>(base + c);
+        a.v[ch][0] = t.x; a.v[ch][1] = t.y; a.v[ch][2] = t.z; a.v[ch][3] = t.w;
+      } else {
+        a.v[ch][0] = a.v[ch][1] = a.v[ch][2] = a.v[ch][3] = 0.f;
+      }
+    } else {
+      a.v[ch][0] = (c < f) ? base[c] : 0.f;
+    }
+  }
+}
+
+template <class C>
+__device__ __forceinline__ void frag_store_scaled(const Frag<C> &a, float s, float *__restrict__ base, int f, int gl) {
+#pragma unroll
+  for (int ch = 0; ch < C::NCH; ++ch) {
+    const int c = (ch * C::G + gl) * C::VEC;
+    if constexpr (C::VEC == 4) {
+      if (c < f)
+        *reinterpret_cast<float4 *>(base + c) =
+            make_float4(a.v[ch][0] * s, a.v[ch][1] * s, a.v[ch][2] * s, a.v[ch][3] * s);
+    } else {
+      if (c < f) base[c] = a.v[ch][0] * s;
+    }
+  }
+}
+
+template <class C>
+__device__ __forceinline__ float frag_dot(const Frag<C> &a, const Frag<C> &b) {
+  float d = 0.f;
+#pragma unroll
+  for (int ch = 0; ch < C::NCH; ++ch)
+#pragma unroll
+    for (int k = 0; k < C::VEC; ++k) d = fmaf(a.v[ch][k], b.v[ch][k], d);
+  return d;
+}
+
+template <class C>
+__device__ __forceinline__ void frag_fma(Frag<C> &acc, float w, const Frag<C> &x) {
+#pragma unroll
+  for (int ch = 0; ch < C::NCH; ++ch)
+#pragma unroll
+    for (int k = 0; k < C::VEC; ++k) acc.v[ch][k] = fmaf(w, x.v[ch][k], acc.v[ch][k]);
+}
+
+template <class C>
+__device__ __forceinline__ void frag_scale(Frag<C> &acc, float s) {
+#pragma unroll
+  for (int ch = 0; ch < C::NCH; ++ch)
+#pragma unroll
+    for (int k = 0; k < C::VEC; ++k) acc.v[ch][k] *= s;
+}
+
+// Sum the EPW per-group partial rows of a wave; afterwards every group holds the total.
+template <class C>
+__device__ __forceinline__ void frag_reduce_groups(Frag<C> &acc) {
+#pragma unroll
+  for (int o = C::G; o < kWave; o <<= 1)
+#pragma unroll
+    for (int ch = 0; ch < C::NCH; ++ch)
+#pragma unroll
+      for (int k = 0; k < C::VEC; ++k) acc.v[ch][k] += __shfl_xor(acc.v[ch][k], o, kWave);
+}
+
+// acc += sum_{e<n} wf(w[e]) * X[cols[e]]  where w/cols are wave-visible arrays (LDS or global) and
+// the wave's EPW groups stride over the n edges.  4 gathers are kept in flight per group.
+template <class C, class WF>
+__device__ __forceinline__ void spmm_accum(Frag<C> &acc, const float *w, const int *cols, int n,
+                                           const float *__restrict__ X, size_t hf, int f, int gid, int gl, WF wf) {
+  int e = gid;
+  for (; e + 3 * C::EPW < n; e += 4 * C::EPW) {
+    const int c0 = cols[e], c1 = cols[e + C::EPW], c2 = cols[e + 2 * C::EPW], c3 = cols[e + 3 * C::EPW];
+    const float w0 = wf(w[e]), w1 = wf(w[e + C::EPW]), w2 = wf(w[e + 2 * C::EPW]), w3 = wf(w[e + 3 * C::EPW]);
+    Frag<C> x0, x1, x2, x3;
+    frag_load<C>(x0, X + (size_t)c0 * hf, f, gl);
+    frag_load<C>(x1, X + (size_t)c1 * hf, f, gl);
+    frag_load<C>(x2, X + (size_t)c2 * hf, f, gl);
+    frag_load<C>(x3, X + (size_t)c3 * hf, f, gl);
+    frag_fma<C>(acc, w0, x0);
+    frag_fma<C>(acc, w1, x1);
+    frag_fma<C>(acc, w2, x2);
+    frag_fma<C>(acc, w3, x3);
+  }
+  for (; e < n; e += C::EPW) {
+    Frag<C> x0;
+    frag_load<C>(x0, X + (size_t)cols[e] * hf, f, gl);
+    frag_fma<C>(acc, wf(w[e]), x0);
+  }
+}
+template <class C>
+__device__ __forceinline__ void spmm_accum(Frag<C> &acc, const float *w, const int *cols, int n,
+                                           const float *__restrict__ X, size_t hf, int f, int gid, int gl) {
+  spmm_accum<C>(acc, w, cols, n, X, hf, f, gid, gl, [](float x) { return x; });
+}
+
+// One online-softmax step for a tile of nt (<= 64) logits, one per lane (lanes >= nt hold -inf).
+// Writes the un-normalised probabilities exp(s - m_new) to sw[lane], rescales acc, updates m, l.
+template <class C>
+__device__ __forceinline__ void online_step(float s, int lane, float *sw, Frag<C> &acc, float &m_run, float &l_run) {
+  const float tmax = lanes_max<kWave>(s);
+  const float m_new = fmaxf(m_run, tmax);
+  // m_run == -inf on the first tile: nothing accumulated yet, the rescale factor is irrelevant (0).
+  const float scale = (m_run == -INFINITY) ? 0.f : fast_exp(m_run - m_new);
+  const float p = (s == -INFINITY) ? 0.f : fast_exp(s - m_new);
+  sw[lane] = p;
+  l_run = l_run * scale + lanes_sum<kWave>(p);
+  frag_scale<C>(acc, scale);
+  m_run = m_new;
+}
+
+__device__ __forceinline__ float leaky_relu(float x, float slope) { return x > 0.f ? x : x * slope; }
+
+}  // namespace dfgnn

@@ -1,0 +1,76 @@
+// dfgnn_launch.hpp -- host-side plumbing shared by the launcher translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "dfgnn_device.hpp"
+
+namespace dfgnn {
+
+struct Csr {
+  int m, nnz, h, f;
+  const int *row_ptr;
+  const int *col_ind;
+  const int *rows;   // sorted COO row ids (hyper / softmax formats), may be null for CSR-only ops
+  const float *val;  // may be null (all ones)
+};
+
+constexpr int kErrBadArg = -1;
+constexpr int kErrUnsupported = -2;
+
+// Rows handled by one workgroup of the hyper-format kernels, and the LDS budget (floats) for the
+// workgroup's edge logits.  A workgroup whose rows hold more edges than kHyperCap does not use the
+// LDS path: its waves run the online (tiled) row routine instead, so there is no degree limit
+// (the reference hard-codes 128 neighbours/row and overflows).
+constexpr int kHyperRows = 16;
+constexpr int kHyperCap = 4096;
+// per-wave scratch for the online routine: 64 weights + 64 column ids
+constexpr int kScratchFloatsPerWave = 2 * kWave;
+
+inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// Pick the lane layout for feature width f.  vec4 requires f % 4 == 0 and 16-byte aligned bases.
+// fn is a generic lambda taking a FeatCfg value; returns its int result, or kErrUnsupported.
+template <class F>
+int dispatch_cfg(int f, bool vec4, F &&fn) {
+  if (vec4) {
+    if (f <= 16) return fn(FeatCfg<4, 4, 1>{});
+    if (f <= 32) return fn(FeatCfg<8, 4, 1>{});
+    if (f <= 64) return fn(FeatCfg<16, 4, 1>{});
+    if (f <= 128) return fn(FeatCfg<32, 4, 1>{});
+    if (f <= 256) return fn(FeatCfg<64, 4, 1>{});
+    if (f <= 512) return fn(FeatCfg<64, 4, 2>{});
+    if (f <= 1024) return fn(FeatCfg<64, 4, 4>{});
+    return kErrUnsupported;
+  }
+  if (f <= 8) return fn(FeatCfg<8, 1, 1>{});
+  if (f <= 16) return fn(FeatCfg<16, 1, 1>{});
+  if (f <= 32) return fn(FeatCfg<32, 1, 1>{});
+  if (f <= 64) return fn(FeatCfg<64, 1, 1>{});
+  if (f <= 128) return fn(FeatCfg<64, 1, 2>{});
+  if (f <= 256) return fn(FeatCfg<64, 1, 4>{});
+  return kErrUnsupported;
+}
+
+inline int launch_status() { return static_cast<int>(hipGetLastError()); }
+
+// ---- launchers implemented in the kernel translation units -----------------------------------
+int launch_gt_hyper_fwd(const Csr &g, const float *Q, const float *K, const float *V, float *attn_edge,
+                        float *out, hipStream_t s);
+int launch_gt_tiling_fwd(const Csr &g, const float *Q, const float *K, const float *V, float *out,
+                         hipStream_t s);
+int launch_gt_sddmm(const Csr &g, const float *Q, const float *K, float *logits, hipStream_t s);
+int launch_softmax_spmm(const Csr &g, const float *logits, const float *X, float *out, bool use_lds,
+                        hipStream_t s);
+int launch_gt_bwd_rows(const Csr &g, const float *K, const float *V, const float *attn_edge,
+                       const float *grad_out, float *grad_edge, float *dQ, hipStream_t s);
+int launch_gt_bwd_cols(const Csr &g, const int *col_ptr, const int *row_ind, const int *val_idx, const float *Q,
+                       const float *attn_edge, const float *grad_edge, const float *grad_out, float *dK,
+                       float *dV, hipStream_t s);
+int launch_gat_hyper_fwd(const Csr &g, const float *attn_row, const float *attn_col, float slope,
+                         const float *X, float *out, hipStream_t s);
+int launch_gat_tiling_fwd(const Csr &g, const float *attn_row, const float *attn_col, float slope,
+                          const float *X, float *out, hipStream_t s);
+int launch_gat_sddmm(const Csr &g, const float *attn_row, const float *attn_col, float slope, float *logits,
+                     hipStream_t s);
+
+}  // namespace dfgnn

@@ -1,0 +1,65 @@
+"""Loader for libdfgnn.so -- the C-ABI HIP library (include/dfgnn.h).
+
+There is deliberately NO fallback: if the shared library is missing or a symbol is absent this
+module raises, so a GPU box can never silently run a non-HIP path.
+"""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdfgnn.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+_vp, _i, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
+
+# symbol -> argtypes; mirrors include/dfgnn.h one to one (checked by tests/test_capi_symbols.py)
+SIGNATURES = {
+    "dfgnn_gt_hyper_fwd": [_i, _i, _i, _i] + [_vp] * 10,
+    "dfgnn_gt_bwd": [_i, _i, _i, _i] + [_vp] * 17,
+    "dfgnn_gt_bwd_rows": [_i, _i, _i, _i] + [_vp] * 11,
+    "dfgnn_gt_bwd_cols": [_i, _i, _i, _i] + [_vp] * 11,
+    "dfgnn_gt_tiling_fwd": [_i, _i, _i, _i] + [_vp] * 8,
+    "dfgnn_gt_softmax_fwd": [_i, _i, _i, _i] + [_vp] * 10,
+    "dfgnn_gt_softmax_gm_fwd": [_i, _i, _i, _i] + [_vp] * 10,
+    "dfgnn_gat_hyper_fwd": [_i, _i, _i, _i] + [_vp] * 5 + [_f] + [_vp] * 3,
+    "dfgnn_gat_softmax_fwd": [_i, _i, _i, _i] + [_vp] * 5 + [_f] + [_vp] * 4,
+    "dfgnn_gat_softmax_gm_fwd": [_i, _i, _i, _i] + [_vp] * 5 + [_f] + [_vp] * 4,
+    "dfgnn_gat_tiling_fwd": [_i, _i, _i, _i] + [_vp] * 4 + [_f] + [_vp] * 3,
+}
+
+_lib = None
+
+
+def build(force=False, jobs=8):
+    """Compile libdfgnn.so for gfx950 with hipcc (recipe: csrc/Makefile)."""
+    cmd = ["make", "-C", CSRC, "-j", str(jobs)]
+    if force:
+        cmd.append("-B")
+    subprocess.check_call(cmd, stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback for the fused kernels.")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, argtypes in SIGNATURES.items():
+            fn = getattr(L, name)  # AttributeError if the library is stale
+            fn.argtypes = argtypes
+            fn.restype = ctypes.c_int
+        L.dfgnn_error_string.argtypes = [ctypes.c_int]
+        L.dfgnn_error_string.restype = ctypes.c_char_p
+        L.dfgnn_abi_version.restype = ctypes.c_int
+        _lib = L
+    return _lib
+
+
+def check(code, what):
+    if code != 0:
+        msg = lib().dfgnn_error_string(code).decode()
+        raise RuntimeError(f"{what} failed: {msg} (code {code})")

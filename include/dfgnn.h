@@ -1,0 +1,124 @@
+/*
+ * dfgnn.h -- C ABI of the MI355X (gfx950) fused attention-GNN convolution library (libdfgnn.so).
+ *
+ * One entry point per live function of the reference's two extension modules
+ * (`fused_gtconv`, `fused_gatconv`).  Plain pointers and sizes only: no torch types, no
+ * allocation, no host synchronisation inside (every call is graph-capturable); the caller
+ * owns all buffers (device memory) and passes the HIP stream to launch on.
+ *
+ * Common conventions (reference: DFGNN/src/fused_gtconv/fused_gtconv_hyper.cu:679-691)
+ *   m        number of nodes  (= row_ptr length - 1)
+ *   nnz      number of edges  (= col_ind length)
+ *   h, f     heads, per-head feature width; features are fp32 [m, h, f] row-major, contiguous
+ *   row_ptr  int32[m+1]  CSR row pointers        col_ind int32[nnz] CSR column ids
+ *   rows     int32[nnz]  sorted COO row ids (the COO half of the "hyper" CSR+COO format:
+ *                        rows[e] = row of CSR edge e); required wherever it appears
+ *   val      fp32[nnz]   edge values multiplied into the GT logits; NULL means all ones
+ *   attn_edge / grad_edge  fp32[h, nnz], head-major, CSR edge order
+ *   stream   hipStream_t (passed as void*), NULL = the legacy default stream
+ *
+ * Return value: 0 on success; a positive value is the hipError_t of the failed launch; a
+ * negative value is one of the DFGNN_E_* argument errors below.  dfgnn_error_string() decodes
+ * both.  Zero-sized problems (m == 0) succeed without launching.
+ *
+ * All functions compute, per head, for every row i with CSR neighbours j (duplicates kept):
+ *   P_e = softmax_j(s_e),  out[i,h,:] = sum_e P_e * V[j,h,:],  empty row -> 0
+ * with s_e = val_e * <Q[i,h,:],K[j,h,:]> (GT) or LeakyReLU(attn_row[i,h] + attn_col[j,h]) (GAT).
+ */
+#ifndef DFGNN_H_
+#define DFGNN_H_
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DFGNN_ABI_VERSION 1
+
+#define DFGNN_E_BADARG (-1)      /* negative size / NULL required pointer                      */
+#define DFGNN_E_UNSUPPORTED (-2) /* feature width outside the compiled range (f > 1024, or     */
+                                 /* f % 4 != 0 with f > 256)                                   */
+
+typedef void *dfgnn_stream_t; /* hipStream_t */
+
+int dfgnn_abi_version(void);
+const char *dfgnn_error_string(int code);
+
+/* ---- GT (graph transformer) ------------------------------------------------------------------
+ * replaces gt_hyper_inference  (DFGNN/src/fused_gtconv/fused_gtconv.cpp:278-314,
+ *                               fused_gtconv_hyper.cu:679-725) when attn_edge == NULL, and
+ *          gt_hyper_forward    (fused_gtconv.cpp:79-116, fused_gtconv_hyper.cu:727-760)
+ *          when attn_edge != NULL (training forward: also writes the normalised attention). */
+int dfgnn_gt_hyper_fwd(int m, int nnz, int h, int f, const int *row_ptr, const int *col_ind,
+                       const int *rows, const float *val, const float *Q, const float *K,
+                       const float *V, float *attn_edge, float *out, dfgnn_stream_t stream);
+
+/* replaces gt_backward (fused_gtconv.cpp:125-172, fused_gtconv_backward.cu:193-265).
+ * col_ptr int32[m+1], row_ind int32[nnz], val_idx int32[nnz] (CSR slot of each CSC entry).
+ * grad_edge is caller-provided scratch fp32[h, nnz] (the reference allocates it inside).
+ * dQ, dK, dV are fully written (no pre-zeroing needed). */
+int dfgnn_gt_bwd(int m, int nnz, int h, int f, const int *row_ptr, const int *col_ind,
+                 const int *rows, const float *val, const int *col_ptr, const int *row_ind,
+                 const int *val_idx, const float *Q, const float *K, const float *V,
+                 const float *attn_edge, const float *grad_out, float *grad_edge, float *dQ,
+                 float *dK, float *dV, dfgnn_stream_t stream);
+
+/* The two launches of dfgnn_gt_bwd, exposed separately so each can be timed / profiled on its own
+ * (dfgnn_gt_bwd == rows pass then cols pass on the same stream):
+ *   rows pass (CSR): dP = <dO[i],V[j]>, dS = P (dP - sum_row P dP) -> grad_edge, dQ   (fused_backward_kernel,
+ *                    fused_gtconv_backward.cu:73-191)
+ *   cols pass (CSC): dV[j] = sum P dO[i], dK[j] = sum dS val Q[i]                      (spmm_backward_kernel,
+ *                    fused_gtconv_backward.cu:40-70) */
+int dfgnn_gt_bwd_rows(int m, int nnz, int h, int f, const int *row_ptr, const int *col_ind,
+                      const int *rows, const float *val, const float *K, const float *V,
+                      const float *attn_edge, const float *grad_out, float *grad_edge, float *dQ,
+                      dfgnn_stream_t stream);
+int dfgnn_gt_bwd_cols(int m, int nnz, int h, int f, const float *val, const int *col_ptr,
+                      const int *row_ind, const int *val_idx, const float *Q, const float *attn_edge,
+                      const float *grad_edge, const float *grad_out, float *dK, float *dV,
+                      dfgnn_stream_t stream);
+
+/* replaces gt_tiling_inference (fused_gtconv.cpp:244-276, fused_gtconv_tiling.cu:92-118):
+ * CSR only, online softmax over fixed-size neighbour tiles, no degree limit. */
+int dfgnn_gt_tiling_fwd(int m, int nnz, int h, int f, const int *row_ptr, const int *col_ind,
+                        const float *val, const float *Q, const float *K, const float *V,
+                        float *out, dfgnn_stream_t stream);
+
+/* replaces gt_softmax_inference (fused_gtconv.cpp:316-352, fused_gtconv_softmax.cu:10-54) and
+ * gt_softmax_gm_inference (fused_gtconv.cpp:354-389, fused_gtconv_softmax_gm.cu:81-125):
+ * two kernels, edge-parallel SDDMM into `logits` (caller scratch fp32[h, nnz]) then
+ * node-parallel softmax+SpMM; the _gm form re-reads logits from global memory on every pass. */
+int dfgnn_gt_softmax_fwd(int m, int nnz, int h, int f, const int *row_ptr, const int *col_ind,
+                         const int *rows, const float *val, const float *Q, const float *K,
+                         const float *V, float *logits, float *out, dfgnn_stream_t stream);
+int dfgnn_gt_softmax_gm_fwd(int m, int nnz, int h, int f, const int *row_ptr, const int *col_ind,
+                            const int *rows, const float *val, const float *Q, const float *K,
+                            const float *V, float *logits, float *out, dfgnn_stream_t stream);
+
+/* ---- GAT ---------------------------------------------------------------------------------------
+ * attn_row, attn_col fp32[m, h]; X (in_feat) fp32[m, h, f].
+ * replaces gat_inference_hyper (DFGNN/src/fused_gatconv/fused_gatconv.cpp:99-119,
+ *                               fused_gatconv_hyper.cu:251-272) */
+int dfgnn_gat_hyper_fwd(int m, int nnz, int h, int f, const int *row_ptr, const int *col_ind,
+                        const int *rows, const float *attn_row, const float *attn_col,
+                        float negative_slope, const float *X, float *out, dfgnn_stream_t stream);
+
+/* replaces gat_inference_softmax (fused_gatconv.cpp:40-61, fused_gatconv_softmax.cu:33-56) and
+ * gat_inference_softmax_gm (fused_gatconv.cpp:69-90, fused_gatconv_softmax_gm.cu) */
+int dfgnn_gat_softmax_fwd(int m, int nnz, int h, int f, const int *row_ptr, const int *col_ind,
+                          const int *rows, const float *attn_row, const float *attn_col,
+                          float negative_slope, const float *X, float *logits, float *out,
+                          dfgnn_stream_t stream);
+int dfgnn_gat_softmax_gm_fwd(int m, int nnz, int h, int f, const int *row_ptr, const int *col_ind,
+                             const int *rows, const float *attn_row, const float *attn_col,
+                             float negative_slope, const float *X, float *logits, float *out,
+                             dfgnn_stream_t stream);
+
+/* replaces gat_inference_tiling (fused_gatconv.cpp:196-219, fused_gatconv_tiling.cu:78-103) */
+int dfgnn_gat_tiling_fwd(int m, int nnz, int h, int f, const int *row_ptr, const int *col_ind,
+                         const float *attn_row, const float *attn_col, float negative_slope,
+                         const float *X, float *out, dfgnn_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DFGNN_H_ */

@@ -1,0 +1,43 @@
+"""CPU: libdfgnn.so loads and exports every symbol include/dfgnn.h declares (no compute calls)."""
+import ctypes
+import os
+import re
+
+from conftest import ROOT
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "dfgnn.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(dfgnn_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_exported():
+    import dfgnn_native
+    assert os.path.exists(dfgnn_native.LIB_PATH), "libdfgnn.so missing: run __graft_entry__.build()"
+    lib = ctypes.CDLL(dfgnn_native.LIB_PATH)
+    names = _declared()
+    assert len(names) >= 11
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/dfgnn.h but not exported"
+
+
+def test_loader_signatures_cover_header():
+    import dfgnn_native
+    compute = [n for n in _declared() if n not in ("dfgnn_abi_version", "dfgnn_error_string")]
+    assert sorted(dfgnn_native.SIGNATURES) == compute
+    lib = dfgnn_native.lib()
+    assert lib.dfgnn_abi_version() == 1
+    assert b"bad argument" in lib.dfgnn_error_string(-1)
+    assert b"unsupported" in lib.dfgnn_error_string(-2)
+
+
+def test_header_arity_matches_loader():
+    """Argument counts in the header equal the ctypes argtypes (catches a drifted binding)."""
+    import dfgnn_native
+    text = open(os.path.join(ROOT, "include", "dfgnn.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    for name, argtypes in dfgnn_native.SIGNATURES.items():
+        m = re.search(r"\bint\s+" + name + r"\s*\((.*?)\)\s*;", text, flags=re.S)
+        assert m, name
+        assert len([a for a in m.group(1).split(",") if a.strip()]) == len(argtypes), name

@@ -1,0 +1,125 @@
+"""CPU: host-side logic -- preprocessing vs scipy, binding checks, baseline (fuse=False) layer
+branches vs the oracle, synthetic generators, and that there is no silent CPU fallback."""
+import argparse
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import torch
+
+import DFGNN  # noqa: F401
+from DFGNN.layers import load_graphconv_layer, load_prepfunc, preprocess_Hyper_fw_bw
+from DFGNN.layers.util import preprocess_CSR, preprocess_Hyper, preprocess_softmax
+from DFGNN.utils import Graph, batch, check_correct, preprocess_dglsp
+from DFGNN.utils import synthetic as S
+
+
+def test_preprocess_matches_scipy_and_oracle(oracle_mod):
+    g = S.pattern_like(batch_size=6, seed=11)
+    src, dst = (t.numpy() for t in g.edges())
+    n = g.num_nodes()
+    A, rows, row_ptr, col_ind, val, col_ptr, row_ind, val_idx, smem = preprocess_Hyper_fw_bw(g)
+    ref = oracle_mod.coo_to_hyper(src, dst, n)
+    for k, t in dict(rows=rows, row_ptr=row_ptr, col_ind=col_ind, col_ptr=col_ptr, row_ind=row_ind,
+                     val_idx=val_idx).items():
+        assert t.dtype == torch.int32
+        np.testing.assert_array_equal(t.numpy(), ref[k], err_msg=k)
+    M = sp.coo_matrix((np.ones(len(src)), (src, dst)), shape=(n, n))
+    csr, csc = M.tocsr(), M.tocsc()
+    np.testing.assert_array_equal(row_ptr.numpy(), csr.indptr)
+    np.testing.assert_array_equal(col_ptr.numpy(), csc.indptr)
+    # val_idx maps CSC slots to CSR slots of the same (row, col) entry
+    r_of = np.repeat(np.arange(n), np.diff(row_ptr.numpy()))
+    np.testing.assert_array_equal(r_of[val_idx.numpy()], row_ind.numpy())
+    c_of = np.repeat(np.arange(n), np.diff(col_ptr.numpy()))
+    np.testing.assert_array_equal(col_ind.numpy()[val_idx.numpy()], c_of)
+    assert smem == 1024 and val.dtype == torch.float32 and bool((val == 1).all())
+    assert len(preprocess_CSR(g)) == 4 and len(preprocess_Hyper(g)) == 5 and len(preprocess_softmax(g)) == 5
+    assert preprocess_Hyper_fw_bw(g, fused=False)[1] is None
+
+
+def test_batch_is_block_diagonal():
+    gs = [S.pattern_like(batch_size=1, seed=s) for s in range(3)]
+    b = batch(gs)
+    assert b.num_nodes() == sum(g.num_nodes() for g in gs)
+    s, d = b.edges()
+    bounds = torch.cumsum(b.batch_num_nodes(), 0)
+    gid = lambda x: torch.bucketize(x, bounds, right=True)  # noqa: E731
+    assert bool((gid(s) == gid(d)).all())
+
+
+def test_generators_shapes():
+    g = S.cora_like()
+    assert g.num_nodes() == 2708 and g.num_edges() == 10556
+    s, d = g.edges()
+    assert bool((s != d).all())
+    g = S.peptides_like(batch_size=8)
+    deg = torch.bincount(g.edges()[0], minlength=g.num_nodes())
+    assert int(deg.max()) <= 5 and int((deg == 0).sum()) >= 1
+    g = S.reddit_like(scale=0.002)
+    assert g.num_edges() % 2 == 0 and g.num_nodes() >= 64
+
+
+def test_binding_rejects_cpu_tensors_and_bad_dtypes():
+    """Error behaviour of the reference binding: RuntimeError '<x> must be on CUDA'
+    (fused_gtconv.cpp:7-13).  There is no CPU fallback."""
+    import fused_gatconv
+    import fused_gtconv
+    ip = torch.tensor([0, 1], dtype=torch.int32)
+    idx = torch.tensor([0], dtype=torch.int32)
+    val = torch.ones(1)
+    q = torch.ones(1, 1, 4)
+    with pytest.raises(RuntimeError, match="must be on CUDA"):
+        fused_gtconv.gt_hyper_inference(ip, idx, idx, val, 1024, q, q, q)
+    with pytest.raises(RuntimeError, match="must be on CUDA"):
+        fused_gtconv.gt_tiling_inference(ip, idx, val, 128, q, q, q)
+    with pytest.raises(RuntimeError, match="must be on CUDA"):
+        fused_gatconv.gat_inference_tiling(torch.ones(1, 1), torch.ones(1, 1), ip, idx, 0.2, q)
+    with pytest.raises(NotImplementedError):
+        fused_gatconv.gat_forward(None, None, None, None, 0.2, None, 0.0)
+
+
+def _args(conv, fmt, dim, heads):
+    return argparse.Namespace(conv=conv, format=fmt, dim=dim, heads=heads)
+
+
+@pytest.mark.parametrize("conv,fmt", [("gt", "hyper"), ("gt", "softmax"), ("gt", "tiling"), ("gt", "softmax_gm"),
+                                      ("gat", "hyper"), ("gat", "softmax"), ("gat", "tiling"),
+                                      ("gat", "softmax_gm")])
+def test_layer_baseline_branch_matches_oracle(oracle_mod, conv, fmt):
+    """fuse=False branch (torch restatement of dgl.sparse) at the layer boundary vs the oracle at the
+    operator boundary, through the layer's own layout transforms."""
+    torch.manual_seed(0)
+    dim, heads = 32, 4
+    layer = load_graphconv_layer(_args(conv, fmt, dim, heads)).eval()
+    assert load_prepfunc(_args(conv, fmt, dim, heads)) is not None
+    g = S.pattern_like(batch_size=3, seed=5)
+    n = g.num_nodes()
+    A = preprocess_dglsp(g)
+    x = torch.randn(n, dim)
+    with torch.no_grad():
+        out, ms = layer(A, x, fuse=False)
+    row_ptr, col_ind, val, _ = preprocess_CSR(g)
+    if conv == "gt":
+        q, k, v = layer.prep_qkv(x)
+        q, k, v = (t.transpose(1, 2).contiguous().detach().numpy() for t in (q, k, v))
+        ref = oracle_mod.gt_forward(row_ptr.numpy(), col_ind.numpy(), val.numpy(), q, k, v)
+        ref = torch.from_numpy(ref).transpose(1, 2).reshape(n, -1)
+        assert out.shape == (n, dim)
+    else:
+        z = layer.W(x).view(-1, layer.out_size, heads).detach()              # baseline layout [N, out, heads]
+        zt = z.transpose(1, 2).contiguous()                                 # operator layout [N, heads, out]
+        a_l, a_r = layer.a_l.transpose(1, 2).detach(), layer.a_r.transpose(1, 2).detach()
+        ar, ac = (a_l * zt).sum(-1), (a_r * zt).sum(-1)
+        ref = oracle_mod.gat_forward(row_ptr.numpy(), col_ind.numpy(), ar.numpy(), ac.numpy(), 0.2, zt.numpy())
+        ref = torch.from_numpy(ref).transpose(1, 2).reshape(n, -1)
+        assert out.shape == (n, dim * heads)
+    assert torch.allclose(out.double(), ref, atol=1e-4)
+    assert check_correct(out, ref.float())
+
+
+def test_layer_factory_errors():
+    with pytest.raises(ValueError):
+        load_graphconv_layer(_args("gt", "cugraph", 8, 1))
+    with pytest.raises(ValueError):
+        load_graphconv_layer(_args("sage", "hyper", 8, 1))
