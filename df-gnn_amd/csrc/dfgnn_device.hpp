@@ -33,16 +33,36 @@ __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// DPP lane permutes (VALU-rate, no LDS crossbar): quad swaps for distance 1 and 2, row_half_mirror
+// and row_mirror pair the two halves of an 8- / 16-lane group -- enough for an all-reduce inside a
+// 16-lane row.  Crossing rows (distance 16, 32) goes through ds_bpermute (__shfl_xor).
+template <int CTRL>
+__device__ __forceinline__ float dpp_perm(float v) {
+  return __builtin_bit_cast(float,
+                            __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+constexpr int kDppXor1 = 0xB1, kDppXor2 = 0x4E, kDppHalfMirror = 0x141, kDppMirror = 0x140;
+
+// All-reduce over aligned groups of W lanes (W a power of two); every lane of the group gets the result.
+// All lanes of the group must be active.
 template <int W>
 __device__ __forceinline__ float lanes_sum(float v) {
-#pragma unroll
-  for (int o = W / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, kWave);
+  if constexpr (W >= 2) v += dpp_perm<kDppXor1>(v);
+  if constexpr (W >= 4) v += dpp_perm<kDppXor2>(v);
+  if constexpr (W >= 8) v += dpp_perm<kDppHalfMirror>(v);
+  if constexpr (W >= 16) v += dpp_perm<kDppMirror>(v);
+  if constexpr (W >= 32) v += __shfl_xor(v, 16, kWave);
+  if constexpr (W >= 64) v += __shfl_xor(v, 32, kWave);
   return v;
 }
 template <int W>
 __device__ __forceinline__ float lanes_max(float v) {
-#pragma unroll
-  for (int o = W / 2; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, kWave));
+  if constexpr (W >= 2) v = fmaxf(v, dpp_perm<kDppXor1>(v));
+  if constexpr (W >= 4) v = fmaxf(v, dpp_perm<kDppXor2>(v));
+  if constexpr (W >= 8) v = fmaxf(v, dpp_perm<kDppHalfMirror>(v));
+  if constexpr (W >= 16) v = fmaxf(v, dpp_perm<kDppMirror>(v));
+  if constexpr (W >= 32) v = fmaxf(v, __shfl_xor(v, 16, kWave));
+  if constexpr (W >= 64) v = fmaxf(v, __shfl_xor(v, 32, kWave));
   return v;
 }
 

@@ -33,12 +33,14 @@ inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 
 template <class F>
 int dispatch_cfg(int f, bool vec4, F &&fn) {
   if (vec4) {
+    // Up to f = 256 a row is held by at most 16 lanes (one DPP row): the SDDMM reduction stays in
+    // VALU-rate DPP ops and a wave touches >= 4 rows per gather instruction.
     if (f <= 16) return fn(FeatCfg<4, 4, 1>{});
     if (f <= 32) return fn(FeatCfg<8, 4, 1>{});
     if (f <= 64) return fn(FeatCfg<16, 4, 1>{});
-    if (f <= 128) return fn(FeatCfg<32, 4, 1>{});
-    if (f <= 256) return fn(FeatCfg<64, 4, 1>{});
-    if (f <= 512) return fn(FeatCfg<64, 4, 2>{});
+    if (f <= 128) return fn(FeatCfg<16, 4, 2>{});
+    if (f <= 256) return fn(FeatCfg<16, 4, 4>{});
+    if (f <= 512) return fn(FeatCfg<32, 4, 4>{});
     if (f <= 1024) return fn(FeatCfg<64, 4, 4>{});
     return kErrUnsupported;
   }
