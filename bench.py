@@ -126,9 +126,11 @@ def main():
         attn = torch.empty(h, nnz, device=dev)
         gedge = torch.empty(h, nnz, device=dev)
         dQ, dK, dV = torch.empty_like(Q), torch.empty_like(Q), torch.empty_like(Q)
+    from _binding_util import get_plan
+    plan, plan_meta = get_plan(row_ptr, col_ind, f, fused_gtconv.USE_BLOCK_PLAN)
     calls = {
         "gt_hyper_fwd": lambda: L.dfgnn_gt_hyper_fwd(m, nnz, h, f, P(row_ptr), P(col_ind), P(rows), P(val), P(Q), P(K),
-                                                     P(V), P(attn), P(out), stream),
+                                                     P(V), P(attn), P(out), plan, plan_meta, stream),
         "gt_bwd_rows": lambda: L.dfgnn_gt_bwd_rows(m, nnz, h, f, P(row_ptr), P(col_ind), P(rows), P(val), P(K), P(V),
                                                    P(attn), P(dO), P(gedge), P(dQ), stream),
         "gt_bwd_cols": lambda: L.dfgnn_gt_bwd_cols(m, nnz, h, f, P(val), P(col_ptr), P(row_ind), P(val_idx), P(Q),

@@ -47,3 +47,58 @@ def stream_ptr(device):
 
 def ptr(t):
     return t.data_ptr() if t is not None else None
+
+
+# ---- block plan cache -----------------------------------------------------------------------------
+class BlockPlan:
+    """Device plan buffer + its 8 host header words (include/dfgnn.h, dfgnn_plan_build)."""
+    __slots__ = ("buf", "meta", "_meta_c", "key")
+
+    def __init__(self, buf, meta_c, key):
+        self.buf, self._meta_c, self.key = buf, meta_c, key
+        self.meta = list(meta_c)
+
+    @property
+    def num_fit(self):
+        return self.meta[0]
+
+    @property
+    def num_spill(self):
+        return self.meta[1]
+
+    def ptrs(self):
+        import ctypes
+        return self.buf.data_ptr(), ctypes.addressof(self._meta_c)
+
+
+def build_plan(indptr, indices, f):
+    """Run dfgnn_plan_build for this CSR structure and feature width (synchronises the stream once)."""
+    import ctypes
+
+    import dfgnn_native as _n
+    m, nnz = indptr.size(0) - 1, indices.size(0)
+    L = _n.lib()
+    with torch.cuda.device(indptr.device):
+        buf = torch.empty(int(L.dfgnn_plan_ints(m)), dtype=torch.int32, device=indptr.device)
+        meta = (ctypes.c_int * 8)()
+        _n.check(L.dfgnn_plan_build(m, nnz, f, indptr.data_ptr(), indices.data_ptr(), buf.data_ptr(),
+                                    ctypes.addressof(meta), stream_ptr(indptr.device)), "dfgnn_plan_build")
+    return BlockPlan(buf, meta, (indices.data_ptr(), nnz, indptr._version, indices._version, f))
+
+
+def get_plan(indptr, indices, f, enable=True):
+    """Plan of (indptr, indices, f), built on first use and cached on the indptr tensor object -- the
+    reference's preprocess_* tuples keep that tensor alive across the layers / epochs that reuse a batch
+    (DFGNN/layers/util.py:82-142), so the plan is built once per batch structure.
+    Returns (plan_ptr, meta_ptr) for the C ABI, or (None, None)."""
+    if not enable or f % 4 != 0 or indices.size(0) == 0:
+        return None, None
+    key = (indices.data_ptr(), indices.size(0), indptr._version, indices._version, f)
+    cache = indptr.__dict__.setdefault("_dfgnn_plans", {})
+    plan = cache.get(f)
+    if plan is None or plan.key != key:
+        plan = build_plan(indptr, indices, f)
+        cache[f] = plan
+    if plan.num_fit == 0:
+        return None, None
+    return plan.ptrs()

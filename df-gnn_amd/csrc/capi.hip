@@ -8,6 +8,17 @@ using namespace dfgnn;
 namespace {
 inline hipStream_t as_stream(dfgnn_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
+// A plan is used only if it was built for exactly this (m, nnz, f) and LDS budget; otherwise the call
+// silently takes the general kernels (same results, no LDS residency).
+inline bool make_plan(Plan &p, const int *plan_dev, const int *meta, int m, int nnz, int f) {
+  p = Plan{nullptr, 0, 0, 0, 0, m, nnz, f};
+  if (!plan_dev || !meta) return false;
+  if (meta[4] != m || meta[5] != nnz || meta[6] != f || meta[7] != kBlockLdsBudget) return false;
+  if (meta[0] <= 0) return false;
+  p = Plan{plan_dev, meta[0], meta[1], meta[2], meta[3], m, nnz, f};
+  return true;
+}
+
 // Returns <0 on a bad argument, 1 when there is nothing to do, 0 to proceed.
 inline int check_common(int m, int nnz, int h, int f, const void *row_ptr, const void *col_ind) {
   if (m < 0 || nnz < 0 || h < 0 || f < 0) return kErrBadArg;
@@ -34,11 +45,17 @@ const char *dfgnn_error_string(int code) {
 
 int dfgnn_gt_hyper_fwd(int m, int nnz, int h, int f, const int *row_ptr, const int *col_ind, const int *rows,
                        const float *val, const float *Q, const float *K, const float *V, float *attn_edge,
-                       float *out, dfgnn_stream_t stream) {
+                       float *out, const int *plan, const int *plan_meta, dfgnn_stream_t stream) {
   if (int c = check_common(m, nnz, h, f, row_ptr, col_ind)) return c < 0 ? c : 0;
   if (!Q || !K || !V || !out || (nnz > 0 && !rows)) return kErrBadArg;
   const Csr g{m, nnz, h, f, row_ptr, col_ind, rows, val};
-  return launch_gt_hyper_fwd(g, Q, K, V, attn_edge, out, as_stream(stream));
+  Plan p;
+  const bool v4 = (f % 4 == 0) && aligned16(Q) && aligned16(K) && aligned16(V) && aligned16(out);
+  if (v4 && block_width_ok(f) && make_plan(p, plan, plan_meta, m, nnz, f)) {
+    if (int rc = launch_gt_block_fwd(g, p, Q, K, V, attn_edge, out, as_stream(stream))) return rc;
+    return launch_gt_hyper_fwd(g, Q, K, V, attn_edge, out, p.spill(), p.num_spill, as_stream(stream));
+  }
+  return launch_gt_hyper_fwd(g, Q, K, V, attn_edge, out, nullptr, 0, as_stream(stream));
 }
 
 int dfgnn_gt_bwd_rows(int m, int nnz, int h, int f, const int *row_ptr, const int *col_ind, const int *rows,

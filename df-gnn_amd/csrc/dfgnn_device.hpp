@@ -66,6 +66,29 @@ __device__ __forceinline__ float lanes_max(float v) {
   return v;
 }
 
+// Whole-wave reductions that never touch the LDS crossbar: in-row all-reduce, then row_bcast15 /
+// row_bcast31 carry the row totals into lane 63, which is read back as a wave-uniform scalar.
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ float dpp_rows(float old, float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old),
+                                                               __builtin_bit_cast(int, v), CTRL, ROWMASK, 0xF, false));
+}
+constexpr int kDppBcast15 = 0x142, kDppBcast31 = 0x143;
+__device__ __forceinline__ float wave_sum(float v) {
+  v = lanes_sum<16>(v);
+  v += dpp_rows<kDppBcast15, 0xA>(0.f, v);
+  v += dpp_rows<kDppBcast31, 0xC>(0.f, v);
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+__device__ __forceinline__ float wave_max(float v) {
+  v = lanes_max<16>(v);
+  v = fmaxf(v, dpp_rows<kDppBcast15, 0xA>(-INFINITY, v));
+  v = fmaxf(v, dpp_rows<kDppBcast31, 0xC>(-INFINITY, v));
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
+typedef float f2v __attribute__((ext_vector_type(2)));
+
 template <int G_, int VEC_, int NCH_>
 struct FeatCfg {
   static constexpr int G = G_;      // lanes per feature row
@@ -139,6 +162,44 @@ __device__ __forceinline__ void frag_fma(Frag<C> &acc, float w, const Frag<C> &x
   for (int ch = 0; ch < C::NCH; ++ch)
 #pragma unroll
     for (int k = 0; k < C::VEC; ++k) acc.v[ch][k] = fmaf(w, x.v[ch][k], acc.v[ch][k]);
+}
+
+// ---- exact-width forms (f == G*VEC*NCH known at compile time): no lane masks, packed FMAs -----------
+template <class C>
+__device__ __forceinline__ void frag_load_full(Frag<C> &a, const float *base, int gl) {
+  static_assert(C::VEC == 4, "exact-width form is float4 only");
+#pragma unroll
+  for (int ch = 0; ch < C::NCH; ++ch) {
+    const float4 t = *reinterpret_cast<const float4 *>(base + (ch * C::G + gl) * 4);
+    a.v[ch][0] = t.x; a.v[ch][1] = t.y; a.v[ch][2] = t.z; a.v[ch][3] = t.w;
+  }
+}
+template <class C>
+__device__ __forceinline__ void frag_store_full(const Frag<C> &a, float s, float *__restrict__ base, int gl) {
+#pragma unroll
+  for (int ch = 0; ch < C::NCH; ++ch)
+    *reinterpret_cast<float4 *>(base + (ch * C::G + gl) * 4) =
+        make_float4(a.v[ch][0] * s, a.v[ch][1] * s, a.v[ch][2] * s, a.v[ch][3] * s);
+}
+template <class C>
+__device__ __forceinline__ float frag_dot_pk(const Frag<C> &a, const Frag<C> &b) {  // v_pk_fma_f32
+  f2v acc = {0.f, 0.f};
+#pragma unroll
+  for (int ch = 0; ch < C::NCH; ++ch) {
+    acc = __builtin_elementwise_fma(f2v{a.v[ch][0], a.v[ch][1]}, f2v{b.v[ch][0], b.v[ch][1]}, acc);
+    acc = __builtin_elementwise_fma(f2v{a.v[ch][2], a.v[ch][3]}, f2v{b.v[ch][2], b.v[ch][3]}, acc);
+  }
+  return acc.x + acc.y;
+}
+template <class C>
+__device__ __forceinline__ void frag_fma_pk(Frag<C> &acc, float w, const Frag<C> &x) {
+  const f2v ww = {w, w};
+#pragma unroll
+  for (int ch = 0; ch < C::NCH; ++ch) {
+    f2v lo = __builtin_elementwise_fma(f2v{x.v[ch][0], x.v[ch][1]}, ww, f2v{acc.v[ch][0], acc.v[ch][1]});
+    f2v hi = __builtin_elementwise_fma(f2v{x.v[ch][2], x.v[ch][3]}, ww, f2v{acc.v[ch][2], acc.v[ch][3]});
+    acc.v[ch][0] = lo.x; acc.v[ch][1] = lo.y; acc.v[ch][2] = hi.x; acc.v[ch][3] = hi.y;
+  }
 }
 
 template <class C>

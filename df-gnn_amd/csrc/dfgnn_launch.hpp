@@ -26,24 +26,43 @@ constexpr int kHyperCap = 4096;
 // per-wave scratch for the online routine: 64 weights + 64 column ids
 constexpr int kScratchFloatsPerWave = 2 * kWave;
 
+// ---- block plan (plan.hip) ---------------------------------------------------------------------
+// One workgroup of kBlockThreads keeps a closed node range's feature rows resident in LDS.
+constexpr int kBlockThreads = 1024;                      // 16 waves, 4 per SIMD
+constexpr int kBlockWaves = kBlockThreads / kWave;
+constexpr int kBlockScratchBytes = kBlockWaves * kWave * 8;  // per-wave (col, weight) staging, 512 B each
+constexpr int kLdsBytes = 160 * 1024;
+constexpr int kBlockLdsBudget = kLdsBytes - kBlockScratchBytes - 256;  // resident rows + edge values + 1/sum
+constexpr int kBlockMergeNodes = 256;                    // small graphs are merged up to this many nodes
+
+struct Plan {              // host view of a built plan (see plan.hip for the device layout)
+  const int *dev;          // device buffer, may be null (= no plan: general kernels only)
+  int num_fit, num_spill, max_fit_nodes, max_fit_edges, m, nnz, f;
+  const int *fit() const { return dev + 8; }
+  const int *spill() const { return dev + 8 + 2 * (size_t)m; }
+};
+
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 // Pick the lane layout for feature width f.  vec4 requires f % 4 == 0 and 16-byte aligned bases.
 // fn is a generic lambda taking a FeatCfg value; returns its int result, or kErrUnsupported.
 template <class F>
+int dispatch_vec4(int f, F &&fn) {
+  // Up to f = 256 a row is held by at most 16 lanes (one DPP row): the SDDMM reduction stays in
+  // VALU-rate DPP ops and a wave touches >= 4 rows per gather instruction.
+  if (f <= 16) return fn(FeatCfg<4, 4, 1>{});
+  if (f <= 32) return fn(FeatCfg<8, 4, 1>{});
+  if (f <= 64) return fn(FeatCfg<16, 4, 1>{});
+  if (f <= 128) return fn(FeatCfg<16, 4, 2>{});
+  if (f <= 256) return fn(FeatCfg<16, 4, 4>{});
+  if (f <= 512) return fn(FeatCfg<32, 4, 4>{});
+  if (f <= 1024) return fn(FeatCfg<64, 4, 4>{});
+  return kErrUnsupported;
+}
+
+template <class F>
 int dispatch_cfg(int f, bool vec4, F &&fn) {
-  if (vec4) {
-    // Up to f = 256 a row is held by at most 16 lanes (one DPP row): the SDDMM reduction stays in
-    // VALU-rate DPP ops and a wave touches >= 4 rows per gather instruction.
-    if (f <= 16) return fn(FeatCfg<4, 4, 1>{});
-    if (f <= 32) return fn(FeatCfg<8, 4, 1>{});
-    if (f <= 64) return fn(FeatCfg<16, 4, 1>{});
-    if (f <= 128) return fn(FeatCfg<16, 4, 2>{});
-    if (f <= 256) return fn(FeatCfg<16, 4, 4>{});
-    if (f <= 512) return fn(FeatCfg<32, 4, 4>{});
-    if (f <= 1024) return fn(FeatCfg<64, 4, 4>{});
-    return kErrUnsupported;
-  }
+  if (vec4) return dispatch_vec4(f, fn);
   if (f <= 8) return fn(FeatCfg<8, 1, 1>{});
   if (f <= 16) return fn(FeatCfg<16, 1, 1>{});
   if (f <= 32) return fn(FeatCfg<32, 1, 1>{});
@@ -57,7 +76,10 @@ inline int launch_status() { return static_cast<int>(hipGetLastError()); }
 
 // ---- launchers implemented in the kernel translation units -----------------------------------
 int launch_gt_hyper_fwd(const Csr &g, const float *Q, const float *K, const float *V, float *attn_edge,
-                        float *out, hipStream_t s);
+                        float *out, const int *chunks, int nchunks, hipStream_t s);
+bool block_width_ok(int f);
+int launch_gt_block_fwd(const Csr &g, const Plan &p, const float *Q, const float *K, const float *V,
+                        float *attn_edge, float *out, hipStream_t s);
 int launch_gt_tiling_fwd(const Csr &g, const float *Q, const float *K, const float *V, float *out,
                          hipStream_t s);
 int launch_gt_sddmm(const Csr &g, const float *Q, const float *K, float *logits, hipStream_t s);

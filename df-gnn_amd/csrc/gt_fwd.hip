@@ -20,7 +20,8 @@ __global__ __launch_bounds__(kBlock) void gt_hyper_fwd_kernel(Csr g, const float
                                                               const float *__restrict__ K,
                                                               const float *__restrict__ V,
                                                               float *__restrict__ attn_edge,
-                                                              float *__restrict__ out) {
+                                                              float *__restrict__ out,
+                                                              const int *__restrict__ chunks) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float *lw = lds;                                    // [kHyperCap] logits of this workgroup's edges
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
@@ -28,8 +29,9 @@ __global__ __launch_bounds__(kBlock) void gt_hyper_fwd_kernel(Csr g, const float
   int *sc = reinterpret_cast<int *>(sw + kWave);
 
   const int head = blockIdx.y;
-  const int r0 = blockIdx.x * kHyperRows;
-  const int r1 = min(g.m, r0 + kHyperRows);
+  // rows of this workgroup: a fixed 16-row slice, or (with a block plan) one spill chunk
+  const int r0 = chunks ? chunks[2 * blockIdx.x] : blockIdx.x * kHyperRows;
+  const int r1 = chunks ? chunks[2 * blockIdx.x + 1] : min(g.m, r0 + kHyperRows);
   const size_t hf = (size_t)g.h * g.f;
   const int f = g.f;
   const float *Qh = Q + (size_t)head * f, *Kh = K + (size_t)head * f, *Vh = V + (size_t)head * f;
@@ -107,15 +109,16 @@ static inline bool vec4_ok(const Csr &g, const float *a, const float *b, const f
 }
 
 int launch_gt_hyper_fwd(const Csr &g, const float *Q, const float *K, const float *V, float *attn_edge,
-                        float *out, hipStream_t s) {
-  const dim3 grid((g.m + kHyperRows - 1) / kHyperRows, g.h);
+                        float *out, const int *chunks, int nchunks, hipStream_t s) {
+  const dim3 grid(chunks ? nchunks : (g.m + kHyperRows - 1) / kHyperRows, g.h);
+  if (grid.x == 0) return 0;
   const size_t lds = sizeof(float) * (kHyperCap + kWavesPerBlock * kScratchFloatsPerWave);
   return dispatch_cfg(g.f, vec4_ok(g, Q, K, V, out), [&](auto cfg) {
     using C = decltype(cfg);
     if (attn_edge)
-      gt_hyper_fwd_kernel<C, true><<<grid, kBlock, lds, s>>>(g, Q, K, V, attn_edge, out);
+      gt_hyper_fwd_kernel<C, true><<<grid, kBlock, lds, s>>>(g, Q, K, V, attn_edge, out, chunks);
     else
-      gt_hyper_fwd_kernel<C, false><<<grid, kBlock, lds, s>>>(g, Q, K, V, nullptr, out);
+      gt_hyper_fwd_kernel<C, false><<<grid, kBlock, lds, s>>>(g, Q, K, V, nullptr, out, chunks);
     return launch_status();
   });
 }

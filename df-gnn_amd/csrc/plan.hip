@@ -1,0 +1,172 @@
+// plan.hip -- block plan of a CSR graph: which contiguous node ranges are "closed" (every edge of
+// a row in the range lands on a column in the range) and small enough for one workgroup to keep the
+// range's K / V (GAT: X) rows resident in LDS.
+//
+// A DGL batch of small graphs is block-diagonal (reference: GraphDataLoader batches in
+// DFGNN/script/test/test_batch_graph.py:67-71), so its closed ranges are the member
+// graphs.  The reference leaves the K/V gathers of such batches to the L2 (fused_gtconv_hyper.cu:
+// 333-337, 399-409); on MI355X one graph's K and V rows fit the 160 KB LDS of a CU, so the hyper
+// kernels run one workgroup per closed range with the gathers served from LDS.  Ranges that do not
+// fit (a full graph such as cora/reddit is a single closed range) are cut into <= 16-row "spill"
+// chunks that run the general row-block kernel.
+//
+// Plan buffer (int32, device), sized by dfgnn_plan_ints(m):
+//   [0 .. 8)            header: num_fit, num_spill, max_fit_nodes, max_fit_edges, m, nnz, f, budget
+//   [8 .. 8+2m)         fit blocks   (n0, n1) pairs
+//   [8+2m .. 8+4m)      spill chunks (r0, r1) pairs, r1 - r0 <= kHyperRows
+//   [8+4m .. )          scratch: lo[m], hi[m], bounds[m+1]
+#include "../../include/dfgnn.h"
+#include "dfgnn_launch.hpp"
+
+namespace dfgnn {
+
+constexpr int kPlanThreads = 1024;
+
+__global__ void plan_row_extent_kernel(int m, const int *__restrict__ row_ptr, const int *__restrict__ col_ind,
+                                       int *__restrict__ lo, int *__restrict__ hi) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  int l = i, h = i;
+  for (int e = row_ptr[i]; e < row_ptr[i + 1]; ++e) {
+    const int c = col_ind[e];
+    l = min(l, c);
+    h = max(h, c);
+  }
+  lo[i] = l;
+  hi[i] = h;
+}
+
+// One workgroup.  (1) hi <- inclusive prefix max, lo <- inclusive suffix min.  (2) boundary after row i
+// iff pmax[i] <= i and smin[i+1] >= i+1.  (3) thread 0 merges consecutive closed ranges greedily while
+// they fit the LDS budget and emits fit blocks / spill chunks.
+__global__ __launch_bounds__(kPlanThreads) void plan_cut_kernel(int m, int nnz, int f, int budget_bytes,
+                                                                int merge_nodes,
+                                                                const int *__restrict__ row_ptr, int *plan) {
+  __shared__ int part[kPlanThreads];
+  int *hdr = plan;
+  int *fit = plan + 8;
+  int *spill = fit + 2 * (size_t)m;
+  int *lo = spill + 2 * (size_t)m;
+  int *hi = lo + m;
+  int *bounds = hi + m;  // [m + 1] ends of the natural closed ranges
+  const int t = threadIdx.x;
+  const int chunk = (m + kPlanThreads - 1) / kPlanThreads;
+  const int b = min(m, t * chunk), e = min(m, b + chunk);
+
+  // prefix max of hi
+  int acc = -1;
+  for (int i = b; i < e; ++i) acc = max(acc, hi[i]);
+  part[t] = acc;
+  __syncthreads();
+  if (t == 0) {
+    int run = -1;
+    for (int k = 0; k < kPlanThreads; ++k) { const int v = part[k]; part[k] = run; run = max(run, v); }
+  }
+  __syncthreads();
+  acc = part[t];
+  for (int i = b; i < e; ++i) { acc = max(acc, hi[i]); hi[i] = acc; }
+  __syncthreads();
+  // suffix min of lo
+  acc = m;
+  for (int i = e - 1; i >= b; --i) acc = min(acc, lo[i]);
+  part[t] = acc;
+  __syncthreads();
+  if (t == 0) {
+    int run = m;
+    for (int k = kPlanThreads - 1; k >= 0; --k) { const int v = part[k]; part[k] = run; run = min(run, v); }
+  }
+  __syncthreads();
+  acc = part[t];
+  for (int i = e - 1; i >= b; --i) { acc = min(acc, lo[i]); lo[i] = acc; }
+  __syncthreads();
+  // count boundaries per thread chunk, scan, write
+  int cnt = 0;
+  for (int i = b; i < e; ++i) cnt += (hi[i] <= i && (i + 1 == m || lo[i + 1] >= i + 1)) ? 1 : 0;
+  part[t] = cnt;
+  __syncthreads();
+  if (t == 0) {
+    int run = 0;
+    for (int k = 0; k < kPlanThreads; ++k) { const int v = part[k]; part[k] = run; run += v; }
+    hdr[7] = run;  // number of natural ranges (temporary)
+  }
+  __syncthreads();
+  int pos = part[t];
+  for (int i = b; i < e; ++i)
+    if (hi[i] <= i && (i + 1 == m || lo[i + 1] >= i + 1)) bounds[pos++] = i + 1;
+  __syncthreads();
+  if (t != 0) return;
+
+  const int nb = hdr[7];
+  int nfit = 0, nspill = 0, maxn = 0, maxe = 0;
+  auto bytes_of = [&](int n0, int n1) -> long {
+    // resident rows + logits + 1/sum + rebased row_ptr + narrowed column ids (gt_block.hip:carve_block_lds)
+    const long n = n1 - n0, ed = row_ptr[n1] - row_ptr[n0];
+    return n * (long)f * 4 + ed * 4 + n * 8 + ed * (n <= 256 ? 1 : 2);
+  };
+  auto flush = [&](int n0, int n1) {
+    if (n1 <= n0) return;
+    fit[2 * nfit] = n0;
+    fit[2 * nfit + 1] = n1;
+    ++nfit;
+    maxn = max(maxn, n1 - n0);
+    maxe = max(maxe, row_ptr[n1] - row_ptr[n0]);
+  };
+  int cur0 = 0, cur1 = 0, prev = 0;
+  for (int k = 0; k < nb; ++k) {
+    const int end = bounds[k];
+    if (bytes_of(prev, end) > budget_bytes) {           // this closed range alone does not fit
+      flush(cur0, cur1);
+      for (int r = prev; r < end; r += kHyperRows) {
+        spill[2 * nspill] = r;
+        spill[2 * nspill + 1] = min(end, r + kHyperRows);
+        ++nspill;
+      }
+      cur0 = cur1 = end;
+    } else if (cur1 > cur0 && (bytes_of(cur0, end) > budget_bytes || end - cur0 > merge_nodes)) {
+      flush(cur0, cur1);
+      cur0 = prev;
+      cur1 = end;
+    } else {
+      if (cur1 == cur0) cur0 = prev;
+      cur1 = end;
+    }
+    prev = end;
+  }
+  flush(cur0, cur1);
+  hdr[0] = nfit;
+  hdr[1] = nspill;
+  hdr[2] = maxn;
+  hdr[3] = maxe;
+  hdr[4] = m;
+  hdr[5] = nnz;
+  hdr[6] = f;
+  hdr[7] = budget_bytes;
+}
+
+}  // namespace dfgnn
+
+using namespace dfgnn;
+
+extern "C" {
+
+size_t dfgnn_plan_ints(int m) { return m < 0 ? 0 : 8 + 7 * (size_t)m + 1; }
+
+int dfgnn_plan_build(int m, int nnz, int f, const int *row_ptr, const int *col_ind, int *plan, int *meta_host,
+                     dfgnn_stream_t stream) {
+  if (m < 0 || nnz < 0 || f <= 0 || !plan || !meta_host) return kErrBadArg;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  for (int k = 0; k < 8; ++k) meta_host[k] = 0;
+  meta_host[4] = m; meta_host[5] = nnz; meta_host[6] = f; meta_host[7] = kBlockLdsBudget;
+  if (m == 0) return 0;
+  if (!row_ptr || (nnz > 0 && !col_ind)) return kErrBadArg;
+  int *lo = plan + 8 + 4 * (size_t)m;
+  int *hi = lo + m;
+  plan_row_extent_kernel<<<(m + 255) / 256, 256, 0, s>>>(m, row_ptr, col_ind, lo, hi);
+  if (int rc = launch_status()) return rc;
+  plan_cut_kernel<<<1, kPlanThreads, 0, s>>>(m, nnz, f, kBlockLdsBudget, kBlockMergeNodes, row_ptr, plan);
+  if (int rc = launch_status()) return rc;
+  if (hipError_t rc = hipMemcpyAsync(meta_host, plan, 8 * sizeof(int), hipMemcpyDeviceToHost, s)) return (int)rc;
+  return (int)hipStreamSynchronize(s);
+}
+
+}  // extern "C"

@@ -15,7 +15,8 @@ _vp, _i, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
 
 # symbol -> argtypes; mirrors include/dfgnn.h one to one (checked by tests/test_capi_symbols.py)
 SIGNATURES = {
-    "dfgnn_gt_hyper_fwd": [_i, _i, _i, _i] + [_vp] * 10,
+    "dfgnn_plan_build": [_i, _i, _i] + [_vp] * 5,
+    "dfgnn_gt_hyper_fwd": [_i, _i, _i, _i] + [_vp] * 12,
     "dfgnn_gt_bwd": [_i, _i, _i, _i] + [_vp] * 17,
     "dfgnn_gt_bwd_rows": [_i, _i, _i, _i] + [_vp] * 11,
     "dfgnn_gt_bwd_cols": [_i, _i, _i, _i] + [_vp] * 11,
@@ -55,6 +56,8 @@ def lib():
         L.dfgnn_error_string.argtypes = [ctypes.c_int]
         L.dfgnn_error_string.restype = ctypes.c_char_p
         L.dfgnn_abi_version.restype = ctypes.c_int
+        L.dfgnn_plan_ints.argtypes = [ctypes.c_int]
+        L.dfgnn_plan_ints.restype = ctypes.c_size_t
         _lib = L
     return _lib
 

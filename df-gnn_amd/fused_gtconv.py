@@ -13,8 +13,11 @@ type (RuntimeError) as the reference.  Differences, all deliberate (SURVEY.md 8b
 import torch
 
 import dfgnn_native as _n
-from _binding_util import (as_int32, check_contiguous, check_device, check_dtype, check_feat3, ptr,
+from _binding_util import (as_int32, check_contiguous, check_device, check_dtype, check_feat3, get_plan, ptr,
                            stream_ptr)
+
+# Set to False to force the general (plan-less) kernels; results are identical either way.
+USE_BLOCK_PLAN = True
 
 
 def _dims(indptr, indices, Q):
@@ -53,9 +56,10 @@ def gt_hyper_inference(indptr, indices, rows, val, smem_consume, Q, K, V):
     _check_edges(nnz, rows=rows, val=val)
     with torch.cuda.device(Q.device):
         out = torch.empty_like(Q)
+        plan, meta = get_plan(indptr, indices, f, USE_BLOCK_PLAN)
         _n.check(_n.lib().dfgnn_gt_hyper_fwd(m, nnz, h, f, ptr(indptr), ptr(indices), ptr(rows), ptr(val),
-                                             ptr(Q), ptr(K), ptr(V), None, ptr(out), stream_ptr(Q.device)),
-                 "gt_hyper_inference")
+                                             ptr(Q), ptr(K), ptr(V), None, ptr(out), plan, meta,
+                                             stream_ptr(Q.device)), "gt_hyper_inference")
     return [out]
 
 
@@ -78,8 +82,9 @@ def gt_hyper_forward(row_ptr, col_ind, rows, val, col_ptr, row_ind, val_idx, sme
     with torch.cuda.device(Q.device):
         out = torch.empty_like(Q)
         attn_edge = torch.empty((h, nnz), dtype=torch.float32, device=Q.device)
+        plan, meta = get_plan(row_ptr, col_ind, f, USE_BLOCK_PLAN)
         _n.check(_n.lib().dfgnn_gt_hyper_fwd(m, nnz, h, f, ptr(row_ptr), ptr(col_ind), ptr(rows), ptr(val),
-                                             ptr(Q), ptr(K), ptr(V), ptr(attn_edge), ptr(out),
+                                             ptr(Q), ptr(K), ptr(V), ptr(attn_edge), ptr(out), plan, meta,
                                              stream_ptr(Q.device)), "gt_hyper_forward")
     return [out, attn_edge]
 

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define DFGNN_ABI_VERSION 1
+#define DFGNN_ABI_VERSION 2
 
 #define DFGNN_E_BADARG (-1)      /* negative size / NULL required pointer                      */
 #define DFGNN_E_UNSUPPORTED (-2) /* feature width outside the compiled range (f > 1024, or     */
@@ -43,14 +43,34 @@ typedef void *dfgnn_stream_t; /* hipStream_t */
 int dfgnn_abi_version(void);
 const char *dfgnn_error_string(int code);
 
+/* ---- block plan (optional, MI355X-specific; no counterpart in the reference) --------------------
+ * A batch of small graphs (DGL GraphDataLoader, DFGNN/script/test/test_batch_graph.py:67-71) is a
+ * block-diagonal adjacency: each member graph is a contiguous node range whose edges stay inside it.
+ * dfgnn_plan_build finds those closed ranges on the GPU and marks the ones whose feature rows
+ * (f floats per node and head) plus per-edge scratch fit one CU's 160 KB LDS; the 'hyper' entry points
+ * that accept a plan then run one workgroup per range with K/V (GAT: X) resident in LDS, and cut
+ * everything else into 16-row chunks for the general kernels.  Results are identical with or
+ * without a plan.  The plan depends on the graph structure and on f only; build it once per batch
+ * (it belongs to preprocessing, like the reference's preprocess_Hyper, DFGNN/layers/util.py:82-100).
+ *   plan       device buffer of dfgnn_plan_ints(m) int32
+ *   meta_host  host buffer of 8 int32 filled on return: num_fit, num_spill, max_fit_nodes,
+ *              max_fit_edges, m, nnz, f, lds_budget
+ * dfgnn_plan_build synchronises `stream` (it copies the 8 header words back); nothing else in this
+ * library does. */
+size_t dfgnn_plan_ints(int m);
+int dfgnn_plan_build(int m, int nnz, int f, const int *row_ptr, const int *col_ind, int *plan,
+                     int *meta_host, dfgnn_stream_t stream);
+
 /* ---- GT (graph transformer) ------------------------------------------------------------------
  * replaces gt_hyper_inference  (DFGNN/src/fused_gtconv/fused_gtconv.cpp:278-314,
  *                               fused_gtconv_hyper.cu:679-725) when attn_edge == NULL, and
  *          gt_hyper_forward    (fused_gtconv.cpp:79-116, fused_gtconv_hyper.cu:727-760)
- *          when attn_edge != NULL (training forward: also writes the normalised attention). */
+ *          when attn_edge != NULL (training forward: also writes the normalised attention).
+ * plan / plan_meta: device plan + its 8 host header words from dfgnn_plan_build, or NULL/NULL. */
 int dfgnn_gt_hyper_fwd(int m, int nnz, int h, int f, const int *row_ptr, const int *col_ind,
                        const int *rows, const float *val, const float *Q, const float *K,
-                       const float *V, float *attn_edge, float *out, dfgnn_stream_t stream);
+                       const float *V, float *attn_edge, float *out, const int *plan,
+                       const int *plan_meta, dfgnn_stream_t stream);
 
 /* replaces gt_backward (fused_gtconv.cpp:125-172, fused_gtconv_backward.cu:193-265).
  * col_ptr int32[m+1], row_ind int32[nnz], val_idx int32[nnz] (CSR slot of each CSC entry).

@@ -274,3 +274,105 @@ def test_non_default_stream_and_error_paths():
     with pytest.raises(RuntimeError, match="unsupported"):
         big = torch.zeros(2, 1, 2048, device=DEV)
         gt.gt_hyper_inference(ip, idx, rows, val, 1024, big, big, big)
+
+
+# ---- block plan (LDS-resident per-graph kernels) ------------------------------------------------
+def _natural_ranges(row_ptr, col_ind):
+    """Closed contiguous node ranges, computed the slow obvious way on the host."""
+    m = len(row_ptr) - 1
+    hi = np.arange(m)
+    lo = np.arange(m)
+    for i in range(m):
+        c = col_ind[row_ptr[i]:row_ptr[i + 1]]
+        if len(c):
+            hi[i] = max(i, c.max())
+            lo[i] = min(i, c.min())
+    pm = np.maximum.accumulate(hi)
+    sm = np.minimum.accumulate(lo[::-1])[::-1]
+    ends = [i + 1 for i in range(m) if pm[i] <= i and (i + 1 == m or sm[i + 1] >= i + 1)]
+    return ends
+
+
+def test_block_plan_structure():
+    from _binding_util import build_plan
+    from DFGNN.layers.util import preprocess_Hyper
+    from DFGNN.utils import synthetic as S
+    g = S.pattern_like(batch_size=40, seed=9)
+    sizes = g.batch_num_nodes().numpy()
+    row_ptr, col_ind, rows, val, smem = preprocess_Hyper(g.to(DEV))
+    plan = build_plan(row_ptr, col_ind, 128)
+    nfit, nspill, maxn, maxe = plan.meta[:4]
+    buf = plan.buf.cpu().numpy()
+    m = g.num_nodes()
+    fit = buf[8:8 + 2 * nfit].reshape(-1, 2)
+    ends = _natural_ranges(row_ptr.cpu().numpy(), col_ind.cpu().numpy())
+    assert nspill == 0 and nfit >= 1
+    assert fit[0, 0] == 0 and fit[-1, 1] == m and (fit[1:, 0] == fit[:-1, 1]).all()      # a partition of the rows
+    assert set(fit[:, 1]).issubset(set(ends))                                            # cuts only at closed ranges
+    assert set(np.cumsum(sizes)).issuperset(set(fit[:, 1]))                              # = graph boundaries
+    assert maxn == (fit[:, 1] - fit[:, 0]).max() and maxn <= 256
+    rp = row_ptr.cpu().numpy()
+    assert maxe == (rp[fit[:, 1]] - rp[fit[:, 0]]).max()
+    # f = 16: many graphs merge into one block of <= 256 nodes
+    plan16 = build_plan(row_ptr, col_ind, 16)
+    fit16 = plan16.buf.cpu().numpy()[8:8 + 2 * plan16.meta[0]].reshape(-1, 2)
+    assert plan16.meta[0] < nfit and (fit16[:, 1] - fit16[:, 0]).max() <= 256
+    # a full graph is one closed range that cannot fit: everything spills in <= 16-row chunks
+    c = S.cora_like()
+    rp2, ci2, _, _, _ = preprocess_Hyper(c.to(DEV))
+    p2 = build_plan(rp2, ci2, 128)
+    assert p2.meta[0] == 0 and p2.meta[1] == (c.num_nodes() + 15) // 16
+
+
+@pytest.mark.parametrize("h,f,bs", [(1, 128, 24), (4, 32, 24), (2, 64, 10), (1, 16, 60), (1, 256, 6), (1, 512, 3)])
+def test_block_kernels_match_oracle_and_general_path(oracle_mod, h, f, bs):
+    """'hyper' with the block plan (K/V resident in LDS) vs the oracle and vs the plan-less kernels."""
+    import fused_gtconv as gt
+    from DFGNN.layers import preprocess_Hyper_fw_bw
+    from DFGNN.utils import synthetic as S
+    kw = dict(mean_nodes=40, std_nodes=5, lo=30, hi=50, mean_deg=15) if f >= 512 else {}  # must fit 160 KB of LDS
+    g = S.pattern_like(batch_size=bs, seed=21 + f, **kw).to(DEV)
+    A, rows, row_ptr, col_ind, val, col_ptr, row_ind, val_idx, smem = preprocess_Hyper_fw_bw(g)
+    val = (torch.rand_like(val) + 0.5)
+    m = g.num_nodes()
+    Q, K, V = S.gt_features(m, h, f, seed=3, device=DEV)
+    want, want_attn = oracle_mod.gt_forward(row_ptr.cpu().numpy(), col_ind.cpu().numpy(), val.cpu().numpy(),
+                                            Q.cpu().numpy(), K.cpu().numpy(), V.cpu().numpy(), want_attn=True)
+    try:
+        gt.USE_BLOCK_PLAN = True
+        out_p = gt.gt_hyper_inference(row_ptr, col_ind, rows, val, smem, Q, K, V)[0]
+        out_t, attn_t = gt.gt_hyper_forward(row_ptr, col_ind, rows, val, col_ptr, row_ind, val_idx, smem, Q, K, V)
+        assert row_ptr._dfgnn_plans[f].num_fit > 0
+        gt.USE_BLOCK_PLAN = False
+        out_g = gt.gt_hyper_inference(row_ptr, col_ind, rows, val, smem, Q, K, V)[0]
+    finally:
+        gt.USE_BLOCK_PLAN = True
+    _close(out_p, want, "block inference")
+    _close(out_t, want, "block training fwd")
+    _close(attn_t, want_attn, "block attn_edge")
+    assert torch.allclose(out_p, out_g, atol=1e-5, rtol=1e-4)
+
+
+def test_block_plan_mixed_fit_and_spill(oracle_mod):
+    """A batch holding one graph too large for LDS: its rows take the general kernel (spill chunks), the
+    other graphs the resident kernel; isolated nodes form their own closed ranges."""
+    import fused_gtconv as gt
+    from DFGNN.layers.util import preprocess_Hyper
+    from DFGNN.utils import Graph, batch
+    from DFGNN.utils import synthetic as S
+    rng = np.random.default_rng(3)
+    big_n = 700
+    iu, ju = np.triu_indices(big_n, k=1)
+    keep = rng.random(len(iu)) < 0.05
+    big = Graph(np.concatenate([iu[keep], ju[keep]]), np.concatenate([ju[keep], iu[keep]]), big_n)
+    lonely = Graph(np.zeros(0, np.int64), np.zeros(0, np.int64), 5)
+    g = batch([S.pattern_like(batch_size=3, seed=1), big, lonely, S.pattern_like(batch_size=2, seed=2)]).to(DEV)
+    row_ptr, col_ind, rows, val, smem = preprocess_Hyper(g)
+    m = g.num_nodes()
+    Q, K, V = S.gt_features(m, 1, 128, seed=8, device=DEV)
+    out = gt.gt_hyper_inference(row_ptr, col_ind, rows, val, smem, Q, K, V)[0]
+    plan = row_ptr._dfgnn_plans[128]
+    assert plan.num_fit >= 2 and plan.num_spill == (big_n + 15) // 16
+    want = oracle_mod.gt_forward(row_ptr.cpu().numpy(), col_ind.cpu().numpy(), val.cpu().numpy(), Q.cpu().numpy(),
+                                 K.cpu().numpy(), V.cpu().numpy())
+    _close(out, want, "mixed fit/spill")

@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""Profiling helper: run one hot-path entry point a few times on the C3 workload (for rocprofv3).
+usage: python3 tools/run_kernel.py [fwd|bwd|fwd_infer] [iters] [batch_size]"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "df-gnn_amd")):
+    sys.path.insert(0, p)
+import torch  # noqa: E402
+
+import fused_gtconv as gt  # noqa: E402
+from DFGNN.layers import preprocess_Hyper_fw_bw  # noqa: E402
+from DFGNN.utils import synthetic as S  # noqa: E402
+
+what = sys.argv[1] if len(sys.argv) > 1 else "fwd"
+iters = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+bs = int(sys.argv[3]) if len(sys.argv) > 3 else 1024
+dev = "cuda:0"
+g = S.pattern_like(batch_size=bs, seed=1).to(dev)
+A, rows, row_ptr, col_ind, val, col_ptr, row_ind, val_idx, smem = preprocess_Hyper_fw_bw(g)
+m = g.num_nodes()
+Q, K, V = S.gt_features(m, 1, 128, seed=100, device=dev)
+dO = torch.randn_like(Q)
+for _ in range(iters):
+    if what == "fwd_infer":
+        gt.gt_hyper_inference(row_ptr, col_ind, rows, val, smem, Q, K, V)
+    else:
+        out, attn = gt.gt_hyper_forward(row_ptr, col_ind, rows, val, col_ptr, row_ind, val_idx, smem, Q, K, V)
+        if what == "bwd":
+            gt.gt_backward(row_ptr, col_ind, rows, val, col_ptr, row_ind, val_idx, smem, Q, K, V, attn, dO)
+torch.cuda.synchronize()
+print("done", what, iters, m, g.num_edges())
