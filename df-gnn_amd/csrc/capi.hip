@@ -65,7 +65,7 @@ int dfgnn_gt_bwd_rows(int m, int nnz, int h, int f, const int *row_ptr, const in
   if (!K || !V || !grad_out || !dQ) return kErrBadArg;
   if (nnz > 0 && (!rows || !attn_edge || !grad_edge)) return kErrBadArg;
   const Csr g{m, nnz, h, f, row_ptr, col_ind, rows, val};
-  return launch_gt_bwd_rows(g, K, V, attn_edge, grad_out, grad_edge, dQ, as_stream(stream));
+  return launch_gt_bwd_rows(g, K, V, attn_edge, grad_out, grad_edge, dQ, nullptr, 0, as_stream(stream));
 }
 
 int dfgnn_gt_bwd_cols(int m, int nnz, int h, int f, const float *val, const int *col_ptr, const int *row_ind,
@@ -77,19 +77,36 @@ int dfgnn_gt_bwd_cols(int m, int nnz, int h, int f, const float *val, const int 
   if (!col_ptr || !Q || !grad_out || !dK || !dV) return kErrBadArg;
   if (nnz > 0 && (!row_ind || !val_idx || !attn_edge || !grad_edge)) return kErrBadArg;
   const Csr g{m, nnz, h, f, nullptr, nullptr, nullptr, val};
-  return launch_gt_bwd_cols(g, col_ptr, row_ind, val_idx, Q, attn_edge, grad_edge, grad_out, dK, dV,
+  return launch_gt_bwd_cols(g, col_ptr, row_ind, val_idx, Q, attn_edge, grad_edge, grad_out, dK, dV, nullptr, 0,
                             as_stream(stream));
 }
 
 int dfgnn_gt_bwd(int m, int nnz, int h, int f, const int *row_ptr, const int *col_ind, const int *rows,
                  const float *val, const int *col_ptr, const int *row_ind, const int *val_idx, const float *Q,
                  const float *K, const float *V, const float *attn_edge, const float *grad_out,
-                 float *grad_edge, float *dQ, float *dK, float *dV, dfgnn_stream_t stream) {
-  if (int rc = dfgnn_gt_bwd_rows(m, nnz, h, f, row_ptr, col_ind, rows, val, K, V, attn_edge, grad_out, grad_edge,
-                                 dQ, stream))
+                 float *grad_edge, float *dQ, float *dK, float *dV, const int *plan, const int *plan_meta,
+                 dfgnn_stream_t stream) {
+  if (int c = check_common(m, nnz, h, f, row_ptr, col_ind)) return c < 0 ? c : 0;
+  if (!Q || !K || !V || !grad_out || !dQ || !dK || !dV || !col_ptr) return kErrBadArg;
+  if (nnz > 0 && (!rows || !row_ind || !val_idx || !attn_edge || !grad_edge)) return kErrBadArg;
+  const Csr g{m, nnz, h, f, row_ptr, col_ind, rows, val};
+  Plan p;
+  const bool v4 = (f % 4 == 0) && aligned16(Q) && aligned16(K) && aligned16(V) && aligned16(grad_out) &&
+                  aligned16(dQ) && aligned16(dK) && aligned16(dV);
+  const int *chunks = nullptr;
+  int nchunks = 0;
+  if (v4 && block_width_ok(f) && make_plan(p, plan, plan_meta, m, nnz, f)) {
+    if (int rc = launch_gt_block_bwd(g, p, col_ptr, row_ind, val_idx, Q, K, V, attn_edge, grad_out, dQ, dK, dV,
+                                     as_stream(stream)))
+      return rc;
+    if (p.num_spill == 0) return 0;
+    chunks = p.spill();
+    nchunks = p.num_spill;
+  }
+  if (int rc = launch_gt_bwd_rows(g, K, V, attn_edge, grad_out, grad_edge, dQ, chunks, nchunks, as_stream(stream)))
     return rc;
-  return dfgnn_gt_bwd_cols(m, nnz, h, f, val, col_ptr, row_ind, val_idx, Q, attn_edge, grad_edge, grad_out, dK,
-                           dV, stream);
+  return launch_gt_bwd_cols(g, col_ptr, row_ind, val_idx, Q, attn_edge, grad_edge, grad_out, dK, dV, chunks,
+                            nchunks, as_stream(stream));
 }
 
 int dfgnn_gt_tiling_fwd(int m, int nnz, int h, int f, const int *row_ptr, const int *col_ind, const float *val,

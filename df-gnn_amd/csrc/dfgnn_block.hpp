@@ -1,0 +1,165 @@
+// dfgnn_block.hpp -- device helpers shared by the LDS-resident per-range ("block") kernels
+// (gt_block.hip forward, gt_block_bwd.hip backward, gat_block.hip).  See gt_block.hip for the design.
+#pragma once
+#include "dfgnn_launch.hpp"
+#include "dfgnn_rows.hpp"
+
+namespace dfgnn {
+
+
+// Diagnostic build only (-DDFGNN_STAMPS, never shipped): per-workgroup phase boundaries in shader cycles.
+#ifdef DFGNN_STAMPS
+__device__ unsigned long long *dfgnn_stamps = nullptr;
+#define DFGNN_STAMP(k)                                                                            \
+  if (threadIdx.x == 0 && dfgnn_stamps)                                                           \
+    dfgnn_stamps[((size_t)blockIdx.x * gridDim.y + blockIdx.y) * 8 + (k)] = __builtin_amdgcn_s_memtime();
+#else
+#define DFGNN_STAMP(k)
+#endif
+
+struct BlockLds {
+  float *res;            // [n * f]  resident feature rows (K, then V)
+  float *lw;             // [ne]     raw logits, then exp(s - max)
+  float *rinv;           // [n]      1 / row sum
+  int *rp;               // [n + 1]  row_ptr of the range, relative to its first edge
+  unsigned char *cols;   // [ne]     block-local column ids, 1 byte each if n <= 256 else 2 bytes
+  int2 *sc;              // this wave's 64 x (col, weight) staging
+};
+
+// Layout must stay in step with plan.hip:bytes_of() (the plan guarantees it fits 160 KB).
+__device__ __forceinline__ BlockLds carve_block_lds(float *lds, int n, int ne, int f, int wave) {
+  BlockLds b;
+  b.res = lds;
+  b.lw = b.res + (size_t)n * f;
+  b.rinv = b.lw + ((ne + 3) & ~3);
+  b.rp = reinterpret_cast<int *>(b.rinv + ((n + 3) & ~3));
+  b.sc = reinterpret_cast<int2 *>(b.rp + ((n + 1 + 3) & ~3)) + wave * kWave;
+  b.cols = reinterpret_cast<unsigned char *>(reinterpret_cast<int2 *>(b.rp + ((n + 1 + 3) & ~3)) + kBlockWaves * kWave);
+  return b;
+}
+
+// Stage the range's row_ptr (rebased) and column ids (rebased, narrowed) into LDS.
+__device__ __forceinline__ void load_block_index(const BlockLds &L, const Csr &g, int n0, int n, int e0, int ne) {
+  for (int i = threadIdx.x; i <= n; i += kBlockThreads) L.rp[i] = g.row_ptr[n0 + i] - e0;
+  const int *ci = g.col_ind + e0;
+  if (n <= 256) {
+    for (int b = threadIdx.x * 4; b < ne; b += kBlockThreads * 4) {
+      unsigned v = 0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (b + k < ne) v |= (unsigned)(ci[b + k] - n0) << (8 * k);
+      *reinterpret_cast<unsigned *>(L.cols + b) = v;
+    }
+  } else {
+    unsigned short *c16 = reinterpret_cast<unsigned short *>(L.cols);
+    for (int b = threadIdx.x * 2; b < ne; b += kBlockThreads * 2) {
+      unsigned v = (unsigned)(ci[b] - n0);
+      if (b + 1 < ne) v |= (unsigned)(ci[b + 1] - n0) << 16;
+      *reinterpret_cast<unsigned *>(c16 + b) = v;
+    }
+  }
+}
+
+__device__ __forceinline__ int block_col(const BlockLds &L, bool narrow, int e) {
+  return narrow ? (int)L.cols[e] : (int)reinterpret_cast<const unsigned short *>(L.cols)[e];
+}
+
+// Copy n feature rows (f floats each, row stride hf in global memory) into LDS, float4 per lane.
+__device__ __forceinline__ void load_resident(float *res, const float *__restrict__ src, int n, int f, size_t hf) {
+  const int f4 = f >> 2;
+  const int total = n * f4;
+  float4 *dst4 = reinterpret_cast<float4 *>(res);
+  if (hf == (size_t)f) {
+    const float4 *src4 = reinterpret_cast<const float4 *>(src);
+    int idx = threadIdx.x;
+    for (; idx + 3 * kBlockThreads < total; idx += 4 * kBlockThreads) {
+      const float4 a = src4[idx], b = src4[idx + kBlockThreads], c = src4[idx + 2 * kBlockThreads],
+                   d = src4[idx + 3 * kBlockThreads];
+      dst4[idx] = a;
+      dst4[idx + kBlockThreads] = b;
+      dst4[idx + 2 * kBlockThreads] = c;
+      dst4[idx + 3 * kBlockThreads] = d;
+    }
+    for (; idx < total; idx += kBlockThreads) dst4[idx] = src4[idx];
+  } else {
+    for (int idx = threadIdx.x; idx < total; idx += kBlockThreads) {
+      const int row = idx / f4, c = idx - row * f4;
+      dst4[idx] = *reinterpret_cast<const float4 *>(src + (size_t)row * hf + 4 * c);
+    }
+  }
+}
+
+// Logits of one <= 64-edge chunk of a row: group gid handles the chunk's edges gid, gid+EPW, ... (their
+// block-local columns were staged de-interleaved in sci); on return lane (gid, gl) holds the logit of
+// edge gl*EPW + gid of the chunk.  Four iterations (4*EPW edges) per trip keep 4*NCH LDS reads in flight.
+template <class C>
+__device__ __forceinline__ float block_chunk_logits(const float *res, const int *sci, const Frag<C> &q, int nt,
+                                                    int gid, int gl) {
+  constexpr int G = C::G, EPW = C::EPW, F = C::G * C::VEC * C::NCH;
+  const int iters = (nt + EPW - 1) / EPW;
+  float mine = 0.f;
+  for (int it = 0; it < iters; it += 4) {
+    const int4 c4 = *reinterpret_cast<const int4 *>(sci + gid * G + it);  // slots past the chunk hold col 0
+    Frag<C> k0, k1, k2, k3;
+    frag_load_full<C>(k0, res + c4.x * F, gl);
+    frag_load_full<C>(k1, res + c4.y * F, gl);
+    frag_load_full<C>(k2, res + c4.z * F, gl);
+    frag_load_full<C>(k3, res + c4.w * F, gl);
+    float d0 = lanes_sum<G>(frag_dot_pk<C>(q, k0));
+    float d1 = lanes_sum<G>(frag_dot_pk<C>(q, k1));
+    float d2 = lanes_sum<G>(frag_dot_pk<C>(q, k2));
+    float d3 = lanes_sum<G>(frag_dot_pk<C>(q, k3));
+    asm volatile("" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3));  // keep the selects below as v_cndmask
+    const int rel = gl - it;
+    mine = rel == 0 ? d0 : mine;
+    mine = rel == 1 ? d1 : mine;
+    mine = rel == 2 ? d2 : mine;
+    mine = rel == 3 ? d3 : mine;
+  }
+  return mine;
+}
+
+
+// acc += sum_{k<deg} w_k * res[row_k]: the entries of one CSR row (or CSC column) are produced by
+// `entry(k, row, w)` on lane k % 64 of each 64-entry chunk, staged de-interleaved in the wave's scratch and
+// consumed by the EPW lane groups, four iterations (4*EPW entries, 4*NCH LDS reads) per trip.
+template <class C, class EntryFn>
+__device__ __forceinline__ void block_spmm(Frag<C> &acc, const float *res, int2 *sc, int deg, int lane, int gid,
+                                           int gl, EntryFn entry) {
+  constexpr int G = C::G, EPW = C::EPW, F = C::G * C::VEC * C::NCH;
+  const int stage = (lane % EPW) * G + lane / EPW;
+  for (int c0 = 0; c0 < deg; c0 += kWave) {
+    const int nt = min(kWave, deg - c0);
+    float w = 0.f;
+    int row = 0;
+    if (lane < nt) entry(c0 + lane, row, w);
+    sc[stage] = make_int2(row * F, __float_as_int(w));
+    wave_sync();
+    const int iters = (nt + EPW - 1) / EPW;
+    for (int it = 0; it < iters; it += 4) {
+      const int4 a = *reinterpret_cast<const int4 *>(sc + gid * G + it);       // (row offset, w) x 2
+      const int4 b = *reinterpret_cast<const int4 *>(sc + gid * G + it + 2);   // (row offset, w) x 2
+      Frag<C> v0, v1, v2, v3;
+      frag_load_full<C>(v0, res + a.x, gl);
+      frag_load_full<C>(v1, res + a.z, gl);
+      frag_load_full<C>(v2, res + b.x, gl);
+      frag_load_full<C>(v3, res + b.z, gl);
+      frag_fma_pk<C>(acc, __int_as_float(a.y), v0);
+      frag_fma_pk<C>(acc, __int_as_float(a.w), v1);
+      frag_fma_pk<C>(acc, __int_as_float(b.y), v2);
+      frag_fma_pk<C>(acc, __int_as_float(b.w), v3);
+    }
+    wave_sync();
+  }
+}
+
+size_t block_lds_bytes(const Plan &p, int f);
+
+// Raise a kernel's dynamic-LDS ceiling so launches above 64 KB are accepted.
+template <class K>
+static int set_max_lds(K kernel) {
+  return (int)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  kLdsBytes);
+}
+
+}  // namespace dfgnn

@@ -86,10 +86,14 @@ int launch_gt_sddmm(const Csr &g, const float *Q, const float *K, float *logits,
 int launch_softmax_spmm(const Csr &g, const float *logits, const float *X, float *out, bool use_lds,
                         hipStream_t s);
 int launch_gt_bwd_rows(const Csr &g, const float *K, const float *V, const float *attn_edge,
-                       const float *grad_out, float *grad_edge, float *dQ, hipStream_t s);
+                       const float *grad_out, float *grad_edge, float *dQ, const int *chunks, int nchunks,
+                       hipStream_t s);
 int launch_gt_bwd_cols(const Csr &g, const int *col_ptr, const int *row_ind, const int *val_idx, const float *Q,
                        const float *attn_edge, const float *grad_edge, const float *grad_out, float *dK,
-                       float *dV, hipStream_t s);
+                       float *dV, const int *chunks, int nchunks, hipStream_t s);
+int launch_gt_block_bwd(const Csr &g, const Plan &p, const int *col_ptr, const int *row_ind, const int *val_idx,
+                        const float *Q, const float *K, const float *V, const float *attn_edge,
+                        const float *grad_out, float *dQ, float *dK, float *dV, hipStream_t s);
 int launch_gat_hyper_fwd(const Csr &g, const float *attn_row, const float *attn_col, float slope,
                          const float *X, float *out, hipStream_t s);
 int launch_gat_tiling_fwd(const Csr &g, const float *attn_row, const float *attn_col, float slope,

@@ -21,7 +21,8 @@ __global__ __launch_bounds__(kBlock) void gt_bwd_rows_kernel(Csr g, const float 
                                                              const float *__restrict__ attn_edge,
                                                              const float *__restrict__ dO,
                                                              float *__restrict__ grad_edge,
-                                                             float *__restrict__ dQ) {
+                                                             float *__restrict__ dQ,
+                                                             const int *__restrict__ chunks) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float *lw = lds;
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
@@ -29,8 +30,8 @@ __global__ __launch_bounds__(kBlock) void gt_bwd_rows_kernel(Csr g, const float 
   int *sc = reinterpret_cast<int *>(sw + kWave);
 
   const int head = blockIdx.y;
-  const int r0 = blockIdx.x * kHyperRows;
-  const int r1 = min(g.m, r0 + kHyperRows);
+  const int r0 = chunks ? chunks[2 * blockIdx.x] : blockIdx.x * kHyperRows;
+  const int r1 = chunks ? chunks[2 * blockIdx.x + 1] : min(g.m, r0 + kHyperRows);
   const size_t hf = (size_t)g.h * g.f;
   const int f = g.f;
   const float *Kh = K + (size_t)head * f, *Vh = V + (size_t)head * f, *dOh = dO + (size_t)head * f;
@@ -123,7 +124,8 @@ __global__ __launch_bounds__(kBlock) void gt_bwd_cols_kernel(Csr g, const int *_
                                                              const float *__restrict__ attn_edge,
                                                              const float *__restrict__ grad_edge,
                                                              const float *__restrict__ dO,
-                                                             float *__restrict__ dK, float *__restrict__ dV) {
+                                                             float *__restrict__ dK, float *__restrict__ dV,
+                                                             const int *__restrict__ chunks) {
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
   const int head = blockIdx.y;
   const size_t hf = (size_t)g.h * g.f;
@@ -131,7 +133,11 @@ __global__ __launch_bounds__(kBlock) void gt_bwd_cols_kernel(Csr g, const int *_
   const float *Qh = Q + (size_t)head * f, *dOh = dO + (size_t)head * f;
   const float *P_h = attn_edge + (size_t)head * g.nnz, *dS_h = grad_edge + (size_t)head * g.nnz;
   const int gid = lane / C::G, gl = lane % C::G;
-  for (int j = blockIdx.x * kWavesPerBlock + wave; j < g.m; j += gridDim.x * kWavesPerBlock) {
+  // columns of this workgroup: grid-strided over all columns, or (with a block plan) one spill chunk
+  const int jbeg = chunks ? chunks[2 * blockIdx.x] + wave : blockIdx.x * kWavesPerBlock + wave;
+  const int jend = chunks ? chunks[2 * blockIdx.x + 1] : g.m;
+  const int jstep = chunks ? kWavesPerBlock : gridDim.x * kWavesPerBlock;
+  for (int j = jbeg; j < jend; j += jstep) {
     const int lb = col_ptr[j], n = col_ptr[j + 1] - lb;
     Frag<C> aK, aV;
     frag_zero<C>(aK);
@@ -178,24 +184,27 @@ static inline bool bwd_vec4(const Csr &g, const float *a, const float *b, const 
 }
 
 int launch_gt_bwd_rows(const Csr &g, const float *K, const float *V, const float *attn_edge,
-                       const float *grad_out, float *grad_edge, float *dQ, hipStream_t s) {
-  const dim3 grid((g.m + kHyperRows - 1) / kHyperRows, g.h);
+                       const float *grad_out, float *grad_edge, float *dQ, const int *chunks, int nchunks,
+                       hipStream_t s) {
+  const dim3 grid(chunks ? nchunks : (g.m + kHyperRows - 1) / kHyperRows, g.h);
+  if (grid.x == 0) return 0;
   const size_t lds = sizeof(float) * (kHyperCap + kWavesPerBlock * kScratchFloatsPerWave);
   return dispatch_cfg(g.f, bwd_vec4(g, K, V, grad_out, dQ, dQ), [&](auto cfg) {
     using C = decltype(cfg);
-    gt_bwd_rows_kernel<C><<<grid, kBlock, lds, s>>>(g, K, V, attn_edge, grad_out, grad_edge, dQ);
+    gt_bwd_rows_kernel<C><<<grid, kBlock, lds, s>>>(g, K, V, attn_edge, grad_out, grad_edge, dQ, chunks);
     return launch_status();
   });
 }
 
 int launch_gt_bwd_cols(const Csr &g, const int *col_ptr, const int *row_ind, const int *val_idx, const float *Q,
                        const float *attn_edge, const float *grad_edge, const float *grad_out, float *dK,
-                       float *dV, hipStream_t s) {
-  const dim3 grid((g.m + kWavesPerBlock - 1) / kWavesPerBlock, g.h);
+                       float *dV, const int *chunks, int nchunks, hipStream_t s) {
+  const dim3 grid(chunks ? nchunks : (g.m + kWavesPerBlock - 1) / kWavesPerBlock, g.h);
+  if (grid.x == 0) return 0;
   return dispatch_cfg(g.f, bwd_vec4(g, Q, grad_out, dK, dV, dV), [&](auto cfg) {
     using C = decltype(cfg);
     gt_bwd_cols_kernel<C><<<grid, kBlock, 0, s>>>(g, col_ptr, row_ind, val_idx, Q, attn_edge, grad_edge,
-                                                  grad_out, dK, dV);
+                                                  grad_out, dK, dV, chunks);
     return launch_status();
   });
 }

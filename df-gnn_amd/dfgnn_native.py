@@ -17,7 +17,7 @@ _vp, _i, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
 SIGNATURES = {
     "dfgnn_plan_build": [_i, _i, _i] + [_vp] * 5,
     "dfgnn_gt_hyper_fwd": [_i, _i, _i, _i] + [_vp] * 12,
-    "dfgnn_gt_bwd": [_i, _i, _i, _i] + [_vp] * 17,
+    "dfgnn_gt_bwd": [_i, _i, _i, _i] + [_vp] * 19,
     "dfgnn_gt_bwd_rows": [_i, _i, _i, _i] + [_vp] * 11,
     "dfgnn_gt_bwd_cols": [_i, _i, _i, _i] + [_vp] * 11,
     "dfgnn_gt_tiling_fwd": [_i, _i, _i, _i] + [_vp] * 8,

@@ -111,10 +111,11 @@ def gt_backward(row_ptr, col_ind, rows, val, col_ptr, row_ind, val_idx, smem_con
     with torch.cuda.device(Q.device):
         grad_edge = torch.empty((h, nnz), dtype=torch.float32, device=Q.device)
         dQ, dK, dV = torch.empty_like(Q), torch.empty_like(K), torch.empty_like(V)
+        plan, meta = get_plan(row_ptr, col_ind, f, USE_BLOCK_PLAN)
         _n.check(_n.lib().dfgnn_gt_bwd(m, nnz, h, f, ptr(row_ptr), ptr(col_ind), ptr(rows), ptr(val),
                                        ptr(col_ptr), ptr(row_ind), ptr(val_idx), ptr(Q), ptr(K), ptr(V),
                                        ptr(attn_edge), ptr(grad), ptr(grad_edge), ptr(dQ), ptr(dK), ptr(dV),
-                                       stream_ptr(Q.device)), "gt_backward")
+                                       plan, meta, stream_ptr(Q.device)), "gt_backward")
     return [dQ, dK, dV]
 
 

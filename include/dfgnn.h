@@ -74,15 +74,17 @@ int dfgnn_gt_hyper_fwd(int m, int nnz, int h, int f, const int *row_ptr, const i
 
 /* replaces gt_backward (fused_gtconv.cpp:125-172, fused_gtconv_backward.cu:193-265).
  * col_ptr int32[m+1], row_ind int32[nnz], val_idx int32[nnz] (CSR slot of each CSC entry).
- * grad_edge is caller-provided scratch fp32[h, nnz] (the reference allocates it inside).
- * dQ, dK, dV are fully written (no pre-zeroing needed). */
+ * grad_edge is caller-provided scratch fp32[h, nnz] (the reference allocates it inside); with a
+ * plan, ranges that run LDS-resident keep dS on chip and leave their part of grad_edge untouched.
+ * dQ, dK, dV are fully written (no pre-zeroing needed).  plan / plan_meta as in dfgnn_gt_hyper_fwd. */
 int dfgnn_gt_bwd(int m, int nnz, int h, int f, const int *row_ptr, const int *col_ind,
                  const int *rows, const float *val, const int *col_ptr, const int *row_ind,
                  const int *val_idx, const float *Q, const float *K, const float *V,
                  const float *attn_edge, const float *grad_out, float *grad_edge, float *dQ,
-                 float *dK, float *dV, dfgnn_stream_t stream);
+                 float *dK, float *dV, const int *plan, const int *plan_meta,
+                 dfgnn_stream_t stream);
 
-/* The two launches of dfgnn_gt_bwd, exposed separately so each can be timed / profiled on its own
+/* The two launches of the plan-less dfgnn_gt_bwd, exposed separately so each can be timed / profiled on its own
  * (dfgnn_gt_bwd == rows pass then cols pass on the same stream):
  *   rows pass (CSR): dP = <dO[i],V[j]>, dS = P (dP - sum_row P dP) -> grad_edge, dQ   (fused_backward_kernel,
  *                    fused_gtconv_backward.cu:73-191)

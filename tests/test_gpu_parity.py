@@ -351,13 +351,28 @@ def test_block_kernels_match_oracle_and_general_path(oracle_mod, h, f, bs):
     _close(out_t, want, "block training fwd")
     _close(attn_t, want_attn, "block attn_edge")
     assert torch.allclose(out_p, out_g, atol=1e-5, rtol=1e-4)
+    # backward through the resident kernel vs the oracle and vs the general two-launch path
+    dO = torch.randn(m, h, f, generator=torch.Generator().manual_seed(5)).to(DEV)
+    wq, wk, wv = oracle_mod.gt_backward(row_ptr.cpu().numpy(), col_ind.cpu().numpy(), val.cpu().numpy(),
+                                        Q.cpu().numpy(), K.cpu().numpy(), V.cpu().numpy(), dO.cpu().numpy())
+    dQ, dK, dV = gt.gt_backward(row_ptr, col_ind, rows, val, col_ptr, row_ind, val_idx, smem, Q, K, V, attn_t, dO)
+    _close(dQ, wq, "block dQ")
+    _close(dK, wk, "block dK")
+    _close(dV, wv, "block dV")
+    try:
+        gt.USE_BLOCK_PLAN = False
+        gQ, gK, gV = gt.gt_backward(row_ptr, col_ind, rows, val, col_ptr, row_ind, val_idx, smem, Q, K, V, attn_t, dO)
+    finally:
+        gt.USE_BLOCK_PLAN = True
+    for a, b in ((dQ, gQ), (dK, gK), (dV, gV)):
+        assert torch.allclose(a, b, atol=1e-4, rtol=1e-3)
 
 
 def test_block_plan_mixed_fit_and_spill(oracle_mod):
     """A batch holding one graph too large for LDS: its rows take the general kernel (spill chunks), the
     other graphs the resident kernel; isolated nodes form their own closed ranges."""
     import fused_gtconv as gt
-    from DFGNN.layers.util import preprocess_Hyper
+    from DFGNN.layers import preprocess_Hyper_fw_bw
     from DFGNN.utils import Graph, batch
     from DFGNN.utils import synthetic as S
     rng = np.random.default_rng(3)
@@ -367,12 +382,19 @@ def test_block_plan_mixed_fit_and_spill(oracle_mod):
     big = Graph(np.concatenate([iu[keep], ju[keep]]), np.concatenate([ju[keep], iu[keep]]), big_n)
     lonely = Graph(np.zeros(0, np.int64), np.zeros(0, np.int64), 5)
     g = batch([S.pattern_like(batch_size=3, seed=1), big, lonely, S.pattern_like(batch_size=2, seed=2)]).to(DEV)
-    row_ptr, col_ind, rows, val, smem = preprocess_Hyper(g)
+    A, rows, row_ptr, col_ind, val, col_ptr, row_ind, val_idx, smem = preprocess_Hyper_fw_bw(g)
     m = g.num_nodes()
     Q, K, V = S.gt_features(m, 1, 128, seed=8, device=DEV)
-    out = gt.gt_hyper_inference(row_ptr, col_ind, rows, val, smem, Q, K, V)[0]
+    out, attn = gt.gt_hyper_forward(row_ptr, col_ind, rows, val, col_ptr, row_ind, val_idx, smem, Q, K, V)
     plan = row_ptr._dfgnn_plans[128]
     assert plan.num_fit >= 2 and plan.num_spill == (big_n + 15) // 16
-    want = oracle_mod.gt_forward(row_ptr.cpu().numpy(), col_ind.cpu().numpy(), val.cpu().numpy(), Q.cpu().numpy(),
-                                 K.cpu().numpy(), V.cpu().numpy())
-    _close(out, want, "mixed fit/spill")
+    n = lambda t: t.cpu().numpy()  # noqa: E731
+    want, want_attn = oracle_mod.gt_forward(n(row_ptr), n(col_ind), n(val), n(Q), n(K), n(V), want_attn=True)
+    _close(out, want, "mixed fit/spill out")
+    _close(attn, want_attn, "mixed fit/spill attn")
+    dO = torch.randn_like(out)
+    wq, wk, wv = oracle_mod.gt_backward(n(row_ptr), n(col_ind), n(val), n(Q), n(K), n(V), n(dO))
+    dQ, dK, dV = gt.gt_backward(row_ptr, col_ind, rows, val, col_ptr, row_ind, val_idx, smem, Q, K, V, attn, dO)
+    _close(dQ, wq, "mixed dQ")
+    _close(dK, wk, "mixed dK")
+    _close(dV, wv, "mixed dV")
