@@ -1,0 +1,83 @@
+"""CPU, world_size 2, gloo: graph-level sharding + output all-gather (the N > 1 path of bench.py).
+The local compute is injected (the oracle stands in for the HIP operator, which needs a GPU)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from DFGNN.parallel import all_gather_rows, shard_graph, shard_graph_bounds, shard_rows
+from DFGNN.utils import synthetic as S
+
+
+def test_shard_bounds_balanced_and_contiguous():
+    g = S.pattern_like(batch_size=64, seed=2)
+    sizes = g.batch_num_nodes()
+    src, _ = g.edges()
+    off = torch.zeros(len(sizes) + 1, dtype=torch.int64)
+    off[1:] = torch.cumsum(sizes, 0)
+    epg = torch.bincount(torch.bucketize(src, off[1:], right=True), minlength=len(sizes))
+    for world in (1, 2, 4, 8):
+        b = shard_graph_bounds(sizes, epg, world)
+        assert b[0][0] == 0 and b[-1][1] == len(sizes) and all(b[i][1] == b[i + 1][0] for i in range(world - 1))
+        loads = [int(epg[g0:g1].sum()) for g0, g1 in b]
+        assert max(loads) <= 1.35 * (sum(loads) / world)
+        rows = shard_rows(sizes, b)
+        assert rows[-1][1] == g.num_nodes()
+    # shards are self-contained: no edge leaves its shard
+    for rank in range(4):
+        sub, (n0, n1) = shard_graph(g, rank, 4)
+        s, d = sub.edges()
+        assert int(s.min()) >= 0 and int(d.min()) >= 0 and int(s.max()) < n1 - n0 and int(d.max()) < n1 - n0
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import oracle
+        from DFGNN.layers.util import preprocess_Hyper
+        from DFGNN.parallel import ShardedGTConv
+        g = S.pattern_like(batch_size=12, seed=5)
+        Q, K, V = S.gt_features(g.num_nodes(), 2, 16, seed=9)
+        sub, (n0, n1) = shard_graph(g, rank, world)
+
+        def conv(params, q, k, v):  # oracle stands in for the HIP op on CPU
+            indptr, indices, rows, val, smem = params
+            o = oracle.gt_forward(indptr.numpy(), indices.numpy(), val.numpy(), q.numpy(), k.numpy(), v.numpy())
+            return torch.from_numpy(o).float()
+
+        op = ShardedGTConv(conv_fn=conv)
+        full = op(preprocess_Hyper(sub), Q[n0:n1], K[n0:n1], V[n0:n1], gather=True)
+        local = op(preprocess_Hyper(sub), Q[n0:n1], K[n0:n1], V[n0:n1], gather=False)
+        assert local.shape[0] == n1 - n0
+        ip, idx, rows, val, _ = preprocess_Hyper(g)
+        want = oracle.gt_forward(ip.numpy(), idx.numpy(), val.numpy(), Q.numpy(), K.numpy(), V.numpy())
+        err = float(np.abs(full.numpy() - want).max())
+        # uneven first dimensions through all_gather_rows
+        t = torch.full((rank + 1, 3), float(rank))
+        cat = all_gather_rows(t)
+        ok = cat.shape == (sum(range(1, world + 1)), 3) and bool((cat[0] == 0).all()) and bool((cat[-1] == world - 1).all())
+        ret[rank] = (err, full.shape[0], ok)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(240)
+def test_two_rank_shard_and_allgather_matches_single_process(oracle_mod):
+    world = 2
+    ret = mp.get_context("spawn").Manager().dict()
+    mp.spawn(_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    g = S.pattern_like(batch_size=12, seed=5)
+    for rank in range(world):
+        err, rows, ok = ret[rank]
+        assert err < 1e-6 and rows == g.num_nodes() and ok
