@@ -129,10 +129,10 @@ def main():
         gedge = torch.empty(h, nnz, device=dev)
         dQ, dK, dV = torch.empty_like(Q), torch.empty_like(Q), torch.empty_like(Q)
     from _binding_util import get_plan
-    plan, plan_meta = get_plan(row_ptr, col_ind, f, fused_gtconv.USE_BLOCK_PLAN)
+    plan, plan_meta, _ = get_plan(row_ptr, col_ind, f, fused_gtconv.USE_BLOCK_PLAN)
     calls = {
         "gt_hyper_fwd": lambda: L.dfgnn_gt_hyper_fwd(m, nnz, h, f, P(row_ptr), P(col_ind), P(rows), P(val), P(Q), P(K),
-                                                     P(V), P(attn), P(out), plan, plan_meta, stream),
+                                                     P(V), P(attn), None, P(out), plan, plan_meta, stream),
         "gt_bwd": lambda: L.dfgnn_gt_bwd(m, nnz, h, f, P(row_ptr), P(col_ind), P(rows), P(val), P(col_ptr), P(row_ind),
                                          P(val_idx), P(Q), P(K), P(V), P(attn), P(dO), P(gedge), P(dQ), P(dK), P(dV),
                                          plan, plan_meta, stream),

@@ -51,7 +51,7 @@ def ptr(t):
 
 # ---- block plan cache -----------------------------------------------------------------------------
 class BlockPlan:
-    """Device plan buffer + its 8 host header words (include/dfgnn.h, dfgnn_plan_build)."""
+    """Device plan buffer + its 12 host header words (include/dfgnn.h, dfgnn_plan_build)."""
     __slots__ = ("buf", "meta", "_meta_c", "key")
 
     def __init__(self, buf, meta_c, key):
@@ -65,6 +65,10 @@ class BlockPlan:
     @property
     def num_spill(self):
         return self.meta[1]
+
+    @property
+    def num_edge_global(self):
+        return self.meta[8]
 
     def ptrs(self):
         import ctypes
@@ -80,7 +84,7 @@ def build_plan(indptr, indices, f):
     L = _n.lib()
     with torch.cuda.device(indptr.device):
         buf = torch.empty(int(L.dfgnn_plan_ints(m)), dtype=torch.int32, device=indptr.device)
-        meta = (ctypes.c_int * 8)()
+        meta = (ctypes.c_int * 12)()
         _n.check(L.dfgnn_plan_build(m, nnz, f, indptr.data_ptr(), indices.data_ptr(), buf.data_ptr(),
                                     ctypes.addressof(meta), stream_ptr(indptr.device)), "dfgnn_plan_build")
     return BlockPlan(buf, meta, (indices.data_ptr(), nnz, indptr._version, indices._version, f))
@@ -90,9 +94,9 @@ def get_plan(indptr, indices, f, enable=True):
     """Plan of (indptr, indices, f), built on first use and cached on the indptr tensor object -- the
     reference's preprocess_* tuples keep that tensor alive across the layers / epochs that reuse a batch
     (DFGNN/layers/util.py:82-142), so the plan is built once per batch structure.
-    Returns (plan_ptr, meta_ptr) for the C ABI, or (None, None)."""
+    Returns (plan_ptr, meta_ptr, needs_edge_scratch) for the C ABI, or (None, None, False)."""
     if not enable or f % 4 != 0 or indices.size(0) == 0:
-        return None, None
+        return None, None, False
     key = (indices.data_ptr(), indices.size(0), indptr._version, indices._version, f)
     cache = indptr.__dict__.setdefault("_dfgnn_plans", {})
     plan = cache.get(f)
@@ -100,5 +104,5 @@ def get_plan(indptr, indices, f, enable=True):
         plan = build_plan(indptr, indices, f)
         cache[f] = plan
     if plan.num_fit == 0:
-        return None, None
-    return plan.ptrs()
+        return None, None, False
+    return plan.ptrs() + (plan.num_edge_global > 0,)

@@ -11,11 +11,11 @@ inline hipStream_t as_stream(dfgnn_stream_t s) { return reinterpret_cast<hipStre
 // A plan is used only if it was built for exactly this (m, nnz, f) and LDS budget; otherwise the call
 // silently takes the general kernels (same results, no LDS residency).
 inline bool make_plan(Plan &p, const int *plan_dev, const int *meta, int m, int nnz, int f) {
-  p = Plan{nullptr, 0, 0, 0, 0, m, nnz, f};
+  p = Plan{nullptr, 0, 0, 0, 0, m, nnz, f, 0};
   if (!plan_dev || !meta) return false;
   if (meta[4] != m || meta[5] != nnz || meta[6] != f || meta[7] != kBlockLdsBudget) return false;
   if (meta[0] <= 0) return false;
-  p = Plan{plan_dev, meta[0], meta[1], meta[2], meta[3], m, nnz, f};
+  p = Plan{plan_dev, meta[0], meta[1], meta[2], meta[3], m, nnz, f, meta[8]};
   return true;
 }
 
@@ -45,14 +45,15 @@ const char *dfgnn_error_string(int code) {
 
 int dfgnn_gt_hyper_fwd(int m, int nnz, int h, int f, const int *row_ptr, const int *col_ind, const int *rows,
                        const float *val, const float *Q, const float *K, const float *V, float *attn_edge,
-                       float *out, const int *plan, const int *plan_meta, dfgnn_stream_t stream) {
+                       float *edge_ws, float *out, const int *plan, const int *plan_meta,
+                       dfgnn_stream_t stream) {
   if (int c = check_common(m, nnz, h, f, row_ptr, col_ind)) return c < 0 ? c : 0;
   if (!Q || !K || !V || !out || (nnz > 0 && !rows)) return kErrBadArg;
   const Csr g{m, nnz, h, f, row_ptr, col_ind, rows, val};
   Plan p;
   const bool v4 = (f % 4 == 0) && aligned16(Q) && aligned16(K) && aligned16(V) && aligned16(out);
   if (v4 && block_width_ok(f) && make_plan(p, plan, plan_meta, m, nnz, f)) {
-    if (int rc = launch_gt_block_fwd(g, p, Q, K, V, attn_edge, out, as_stream(stream))) return rc;
+    if (int rc = launch_gt_block_fwd(g, p, Q, K, V, attn_edge, edge_ws, out, as_stream(stream))) return rc;
     return launch_gt_hyper_fwd(g, Q, K, V, attn_edge, out, p.spill(), p.num_spill, as_stream(stream));
   }
   return launch_gt_hyper_fwd(g, Q, K, V, attn_edge, out, nullptr, 0, as_stream(stream));
@@ -96,8 +97,8 @@ int dfgnn_gt_bwd(int m, int nnz, int h, int f, const int *row_ptr, const int *co
   const int *chunks = nullptr;
   int nchunks = 0;
   if (v4 && block_width_ok(f) && make_plan(p, plan, plan_meta, m, nnz, f)) {
-    if (int rc = launch_gt_block_bwd(g, p, col_ptr, row_ind, val_idx, Q, K, V, attn_edge, grad_out, dQ, dK, dV,
-                                     as_stream(stream)))
+    if (int rc = launch_gt_block_bwd(g, p, col_ptr, row_ind, val_idx, Q, K, V, attn_edge, grad_out, grad_edge, dQ,
+                                     dK, dV, as_stream(stream)))
       return rc;
     if (p.num_spill == 0) return 0;
     chunks = p.spill();

@@ -17,9 +17,21 @@ __device__ unsigned long long *dfgnn_stamps = nullptr;
 #define DFGNN_STAMP(k)
 #endif
 
+// Per-edge fp32 values of a range (logits / exp values / dS): in LDS when the range's plan entry allows,
+// otherwise in caller-provided global scratch (attn_edge in the training forward, grad_edge in the
+// backward).  Every access is block-uniformly one or the other, so no flat-address instructions are needed.
+struct EdgeArr {
+  float *lds;      // null when the array lives in global memory
+  float *glob;
+  __device__ __forceinline__ float load(int e) const { return lds ? lds[e] : glob[e]; }
+  __device__ __forceinline__ void store(int e, float v) const {
+    if (lds) lds[e] = v; else glob[e] = v;
+  }
+};
+
 struct BlockLds {
   float *res;            // [n * f]  resident feature rows (K, then V)
-  float *lw;             // [ne]     raw logits, then exp(s - max)
+  float *lw;             // [ne]     raw logits, then exp(s - max)   (zero-sized when the edge array is global)
   float *rinv;           // [n]      1 / row sum
   int *rp;               // [n + 1]  row_ptr of the range, relative to its first edge
   unsigned char *cols;   // [ne]     block-local column ids, 1 byte each if n <= 256 else 2 bytes

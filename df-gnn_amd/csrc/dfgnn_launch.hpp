@@ -35,11 +35,14 @@ constexpr int kLdsBytes = 160 * 1024;
 constexpr int kBlockLdsBudget = kLdsBytes - kBlockScratchBytes - 256;  // resident rows + edge values + 1/sum
 constexpr int kBlockMergeNodes = 256;                    // small graphs are merged up to this many nodes
 
+constexpr int kPlanHeader = 12;                          // int32 header words of a plan buffer
+constexpr int kPlanEdgeGlobal = 1 << 30;                 // flag on a fit range's n1: per-edge array in global scratch
+
 struct Plan {              // host view of a built plan (see plan.hip for the device layout)
   const int *dev;          // device buffer, may be null (= no plan: general kernels only)
-  int num_fit, num_spill, max_fit_nodes, max_fit_edges, m, nnz, f;
-  const int *fit() const { return dev + 8; }
-  const int *spill() const { return dev + 8 + 2 * (size_t)m; }
+  int num_fit, num_spill, max_fit_nodes, max_fit_edges, m, nnz, f, num_edge_global;
+  const int *fit() const { return dev + kPlanHeader; }
+  const int *spill() const { return dev + kPlanHeader + 2 * (size_t)m; }
 };
 
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
@@ -79,7 +82,7 @@ int launch_gt_hyper_fwd(const Csr &g, const float *Q, const float *K, const floa
                         float *out, const int *chunks, int nchunks, hipStream_t s);
 bool block_width_ok(int f);
 int launch_gt_block_fwd(const Csr &g, const Plan &p, const float *Q, const float *K, const float *V,
-                        float *attn_edge, float *out, hipStream_t s);
+                        float *attn_edge, float *edge_ws, float *out, hipStream_t s);
 int launch_gt_tiling_fwd(const Csr &g, const float *Q, const float *K, const float *V, float *out,
                          hipStream_t s);
 int launch_gt_sddmm(const Csr &g, const float *Q, const float *K, float *logits, hipStream_t s);
@@ -93,7 +96,7 @@ int launch_gt_bwd_cols(const Csr &g, const int *col_ptr, const int *row_ind, con
                        float *dV, const int *chunks, int nchunks, hipStream_t s);
 int launch_gt_block_bwd(const Csr &g, const Plan &p, const int *col_ptr, const int *row_ind, const int *val_idx,
                         const float *Q, const float *K, const float *V, const float *attn_edge,
-                        const float *grad_out, float *dQ, float *dK, float *dV, hipStream_t s);
+                        const float *grad_out, float *edge_ws, float *dQ, float *dK, float *dV, hipStream_t s);
 int launch_gat_hyper_fwd(const Csr &g, const float *attn_row, const float *attn_col, float slope,
                          const float *X, float *out, hipStream_t s);
 int launch_gat_tiling_fwd(const Csr &g, const float *attn_row, const float *attn_col, float slope,

@@ -26,10 +26,13 @@ __global__ __launch_bounds__(kBlockThreads) void gt_block_fwd_kernel(Csr g, cons
                                                                      const float *__restrict__ K,
                                                                      const float *__restrict__ V,
                                                                      float *__restrict__ attn_edge,
+                                                                     float *__restrict__ edge_ws,
                                                                      float *__restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int G = C::G, EPW = C::EPW, F = C::G * C::VEC * C::NCH;  // F == g.f (checked by the launcher)
-  const int n0 = fit[2 * blockIdx.x], n1 = fit[2 * blockIdx.x + 1];
+  const int n0 = fit[2 * blockIdx.x], n1raw = fit[2 * blockIdx.x + 1];
+  const bool edge_global = (n1raw & kPlanEdgeGlobal) != 0;
+  const int n1 = n1raw & ~kPlanEdgeGlobal;
   const int n = n1 - n0;
   const int head = blockIdx.y;
   const size_t hf = (size_t)g.h * F;
@@ -37,7 +40,9 @@ __global__ __launch_bounds__(kBlockThreads) void gt_block_fwd_kernel(Csr g, cons
   const int ne = g.row_ptr[n1] - e0;
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
   const int gid = lane / G, gl = lane % G;
-  const BlockLds L = carve_block_lds(lds, n, ne, F, wave);
+  const BlockLds L = carve_block_lds(lds, n, edge_global ? 0 : ne, F, wave);
+  // exp values between the passes: LDS, or (large ranges) this range's slice of the global scratch
+  const EdgeArr W{edge_global ? nullptr : L.lw, edge_global ? edge_ws + (size_t)head * g.nnz + e0 : nullptr};
   int *sci = reinterpret_cast<int *>(L.sc);  // pass A stages columns only (first 256 B of the scratch)
   const float *Qh = Q + (size_t)head * F;
   float *outh = out + (size_t)head * F;
@@ -61,7 +66,6 @@ __global__ __launch_bounds__(kBlockThreads) void gt_block_fwd_kernel(Csr g, cons
     const int deg = __builtin_amdgcn_readfirstlane(L.rp[r + 1]) - lb;
     const Frag<C> q = q_next;
     if (r + kBlockWaves < n) frag_load_full<C>(q_next, Qh + (size_t)(n0 + r + kBlockWaves) * hf, gl);
-    float *lrow = L.lw + lb;
     if (deg <= kWave) {
       // the whole row is one chunk: softmax entirely in registers
       const float myval = (g.val && kk < deg) ? g.val[e0 + lb + kk] : 1.f;
@@ -73,7 +77,7 @@ __global__ __launch_bounds__(kBlockThreads) void gt_block_fwd_kernel(Csr g, cons
       const float mx = wave_max(s);
       const float p = (s == -INFINITY) ? 0.f : fast_exp(s - mx);
       const float sum = wave_sum(p);
-      if (kk < deg) lrow[kk] = p;
+      if (kk < deg) W.store(lb + kk, p);
       if (lane == 0) L.rinv[r] = (sum != 0.f) ? 1.f / sum : 0.f;
     } else {
       for (int c0 = 0; c0 < deg; c0 += kWave) {
@@ -83,17 +87,19 @@ __global__ __launch_bounds__(kBlockThreads) void gt_block_fwd_kernel(Csr g, cons
         wave_sync();
         const float mine = block_chunk_logits<C>(L.res, sci, q, nt, gid, gl);
         wave_sync();
-        if (kk < nt) lrow[c0 + kk] = mine * myval;
+        if (kk < nt) W.store(lb + c0 + kk, mine * myval);
       }
       wave_sync();
+      // lane l wrote slot c0 + kk(l) and now reads slot l + 64 j: order the wave's global traffic first
+      if (edge_global) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
       float mx = -INFINITY;
-      for (int e = lane; e < deg; e += kWave) mx = fmaxf(mx, lrow[e]);
+      for (int e = lane; e < deg; e += kWave) mx = fmaxf(mx, W.load(lb + e));
       mx = wave_max(mx);
       float sum = 0.f;
       for (int e = lane; e < deg; e += kWave) {
-        const float s = lrow[e];
+        const float s = W.load(lb + e);
         const float p = (s == -INFINITY) ? 0.f : fast_exp(s - mx);
-        lrow[e] = p;
+        W.store(lb + e, p);
         sum += p;
       }
       sum = wave_sum(sum);
@@ -115,11 +121,10 @@ __global__ __launch_bounds__(kBlockThreads) void gt_block_fwd_kernel(Csr g, cons
     const int lb = __builtin_amdgcn_readfirstlane(L.rp[r]);
     const int deg = __builtin_amdgcn_readfirstlane(L.rp[r + 1]) - lb;
     const float inv = L.rinv[r];
-    const float *lrow = L.lw + lb;
     Frag<C> acc;
     frag_zero<C>(acc);
     block_spmm<C>(acc, L.res, L.sc, deg, lane, gid, gl, [&](int k, int &row, float &w) {
-      w = lrow[k];
+      w = W.load(lb + k);
       row = block_col(L, narrow, lb + k);
       if constexpr (WRITE_ATTN) attn_h[e0 + lb + k] = w * inv;
     });
@@ -134,6 +139,7 @@ __global__ __launch_bounds__(kBlockThreads) void gt_block_fwd_kernel(Csr g, cons
 }
 
 size_t block_lds_bytes(const Plan &p, int f) {
+  if (p.num_edge_global > 0) return kLdsBytes;
   const size_t n = p.max_fit_nodes, e = p.max_fit_edges;
   size_t b = n * f * 4 + (e + 4) * 4 + (n + 4) * 4 + (n + 8) * 4 + kBlockScratchBytes + (e + 4) * 2 + 64;
   return b > (size_t)kLdsBytes ? (size_t)kLdsBytes : b;
@@ -148,18 +154,23 @@ bool block_width_ok(int f) {
 }
 
 int launch_gt_block_fwd(const Csr &g, const Plan &p, const float *Q, const float *K, const float *V,
-                        float *attn_edge, float *out, hipStream_t s) {
+                        float *attn_edge, float *edge_ws, float *out, hipStream_t s) {
   if (p.num_fit == 0) return 0;
+  // Ranges whose exp values do not fit LDS park them in global memory: the training forward lends its own
+  // attn_edge output for that (it is overwritten with the normalised values in pass B), inference needs
+  // the caller's scratch.
+  if (!edge_ws) edge_ws = attn_edge;
+  if (p.num_edge_global > 0 && !edge_ws) return kErrBadArg;
   const dim3 grid(p.num_fit, g.h);
   const size_t lds = block_lds_bytes(p, g.f);
   return dispatch_vec4(g.f, [&](auto cfg) {
     using C = decltype(cfg);
     if (attn_edge) {
       if (int rc = set_max_lds(gt_block_fwd_kernel<C, true>)) return rc;
-      gt_block_fwd_kernel<C, true><<<grid, kBlockThreads, lds, s>>>(g, p.fit(), Q, K, V, attn_edge, out);
+      gt_block_fwd_kernel<C, true><<<grid, kBlockThreads, lds, s>>>(g, p.fit(), Q, K, V, attn_edge, edge_ws, out);
     } else {
       if (int rc = set_max_lds(gt_block_fwd_kernel<C, false>)) return rc;
-      gt_block_fwd_kernel<C, false><<<grid, kBlockThreads, lds, s>>>(g, p.fit(), Q, K, V, nullptr, out);
+      gt_block_fwd_kernel<C, false><<<grid, kBlockThreads, lds, s>>>(g, p.fit(), Q, K, V, nullptr, edge_ws, out);
     }
     return launch_status();
   });

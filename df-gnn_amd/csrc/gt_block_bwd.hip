@@ -26,11 +26,11 @@ struct BwdLds {
   bool staged;
 };
 
-__device__ __forceinline__ BwdLds carve_bwd_lds(float *lds, int n, int ne, int f, int wave) {
+__device__ __forceinline__ BwdLds carve_bwd_lds(float *lds, int n, int ne, int ne_lds, int f, int wave) {
   BwdLds b;
   b.res = lds;
   b.lw = b.res + (size_t)n * f;
-  b.rp = reinterpret_cast<int *>(b.lw + ((ne + 3) & ~3));
+  b.rp = reinterpret_cast<int *>(b.lw + ((ne_lds + 3) & ~3));
   b.cp = b.rp + ((n + 1 + 3) & ~3);
   int2 *sc0 = reinterpret_cast<int2 *>(b.cp + ((n + 1 + 3) & ~3));
   b.sc = sc0 + wave * kWave;
@@ -50,10 +50,12 @@ __global__ __launch_bounds__(kBlockThreads) void gt_block_bwd_kernel(
     Csr g, const int *__restrict__ fit, const int *__restrict__ col_ptr, const int *__restrict__ row_ind,
     const int *__restrict__ val_idx, const float *__restrict__ Q, const float *__restrict__ K,
     const float *__restrict__ V, const float *__restrict__ attn_edge, const float *__restrict__ dO,
-    float *__restrict__ dQ, float *__restrict__ dK, float *__restrict__ dV) {
+    float *__restrict__ edge_ws, float *__restrict__ dQ, float *__restrict__ dK, float *__restrict__ dV) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int G = C::G, EPW = C::EPW, F = C::G * C::VEC * C::NCH;
-  const int n0 = fit[2 * blockIdx.x], n1 = fit[2 * blockIdx.x + 1];
+  const int n0 = fit[2 * blockIdx.x], n1raw = fit[2 * blockIdx.x + 1];
+  const bool edge_global = (n1raw & kPlanEdgeGlobal) != 0;
+  const int n1 = n1raw & ~kPlanEdgeGlobal;
   const int n = n1 - n0;
   const int head = blockIdx.y;
   const size_t hf = (size_t)g.h * F;
@@ -62,7 +64,9 @@ __global__ __launch_bounds__(kBlockThreads) void gt_block_bwd_kernel(
   const int ce0 = col_ptr[n0];  // == e0 for a closed range; kept separate for clarity
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
   const int gid = lane / G, gl = lane % G;
-  const BwdLds L = carve_bwd_lds(lds, n, ne, F, wave);
+  const BwdLds L = carve_bwd_lds(lds, n, ne, edge_global ? 0 : ne, F, wave);
+  // dP, then dS * val, per edge of the range: LDS, or (large ranges) the caller's grad_edge scratch
+  const EdgeArr W{edge_global ? nullptr : L.lw, edge_global ? edge_ws + (size_t)head * g.nnz + e0 : nullptr};
   int *sci = reinterpret_cast<int *>(L.sc);
   const bool narrow = n <= 256;
   const int kk = gl * EPW + gid;
@@ -121,7 +125,6 @@ __global__ __launch_bounds__(kBlockThreads) void gt_block_bwd_kernel(
       const int deg = __builtin_amdgcn_readfirstlane(L.rp[r + 1]) - lb;
       const Frag<C> go = g_next;
       if (r + kBlockWaves < n) frag_load_full<C>(g_next, dOh + (size_t)(n0 + r + kBlockWaves) * hf, gl);
-      float *lrow = L.lw + lb;
       if (deg <= kWave) {
         const bool mine_ok = kk < deg;
         const float pk = mine_ok ? P_h[lb + kk] : 0.f;
@@ -131,7 +134,7 @@ __global__ __launch_bounds__(kBlockThreads) void gt_block_bwd_kernel(
         const float dp = block_chunk_logits<C>(L.res, sci, go, deg, gid, gl);
         wave_sync();
         const float t = wave_sum(mine_ok ? pk * dp : 0.f);
-        if (mine_ok) lrow[kk] = pk * (dp - t) * vk;
+        if (mine_ok) W.store(lb + kk, pk * (dp - t) * vk);
       } else {
         float tacc = 0.f;
         for (int c0 = 0; c0 < deg; c0 += kWave) {
@@ -142,15 +145,16 @@ __global__ __launch_bounds__(kBlockThreads) void gt_block_bwd_kernel(
           const float dp = block_chunk_logits<C>(L.res, sci, go, nt, gid, gl);
           wave_sync();
           if (kk < nt) {
-            lrow[c0 + kk] = dp;
+            W.store(lb + c0 + kk, dp);
             tacc = fmaf(pk, dp, tacc);
           }
         }
         const float t = wave_sum(tacc);
         wave_sync();
+        if (edge_global) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         for (int e = lane; e < deg; e += kWave) {
-          const float ds = P_h[lb + e] * (lrow[e] - t);
-          lrow[e] = valb ? ds * valb[lb + e] : ds;
+          const float ds = P_h[lb + e] * (W.load(lb + e) - t);
+          W.store(lb + e, valb ? ds * valb[lb + e] : ds);
         }
       }
     }
@@ -163,11 +167,10 @@ __global__ __launch_bounds__(kBlockThreads) void gt_block_bwd_kernel(
   for (int r = wave; r < n; r += kBlockWaves) {
     const int lb = __builtin_amdgcn_readfirstlane(L.rp[r]);
     const int deg = __builtin_amdgcn_readfirstlane(L.rp[r + 1]) - lb;
-    const float *lrow = L.lw + lb;
     Frag<C> acc;
     frag_zero<C>(acc);
     block_spmm<C>(acc, L.res, L.sc, deg, lane, gid, gl, [&](int k, int &row, float &w) {
-      w = lrow[k];
+      w = W.load(lb + k);
       row = col_of(lb + k);
     });
     frag_reduce_groups<C>(acc);
@@ -215,7 +218,7 @@ __global__ __launch_bounds__(kBlockThreads) void gt_block_bwd_kernel(
     block_spmm<C>(acc, L.res, L.sc, cdeg, lane, gid, gl, [&](int k, int &row, float &w) {
       int slot;
       csc_entry(cb + k, row, slot);
-      w = L.lw[slot];
+      w = W.load(slot);
     });
     frag_reduce_groups<C>(acc);
     if (gid == 0) frag_store_full<C>(acc, 1.f, dK + (size_t)(n0 + c) * hf + hoff, gl);
@@ -224,14 +227,15 @@ __global__ __launch_bounds__(kBlockThreads) void gt_block_bwd_kernel(
 
 int launch_gt_block_bwd(const Csr &g, const Plan &p, const int *col_ptr, const int *row_ind, const int *val_idx,
                         const float *Q, const float *K, const float *V, const float *attn_edge,
-                        const float *grad_out, float *dQ, float *dK, float *dV, hipStream_t s) {
+                        const float *grad_out, float *edge_ws, float *dQ, float *dK, float *dV, hipStream_t s) {
   if (p.num_fit == 0) return 0;
+  if (p.num_edge_global > 0 && !edge_ws) return kErrBadArg;
   const dim3 grid(p.num_fit, g.h);
   return dispatch_vec4(g.f, [&](auto cfg) {
     using C = decltype(cfg);
     if (int rc = set_max_lds(gt_block_bwd_kernel<C>)) return rc;
     gt_block_bwd_kernel<C><<<grid, kBlockThreads, kLdsBytes, s>>>(g, p.fit(), col_ptr, row_ind, val_idx, Q, K, V,
-                                                                  attn_edge, grad_out, dQ, dK, dV);
+                                                                  attn_edge, grad_out, edge_ws, dQ, dK, dV);
     return launch_status();
   });
 }

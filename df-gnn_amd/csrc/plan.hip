@@ -11,10 +11,11 @@
 // chunks that run the general row-block kernel.
 //
 // Plan buffer (int32, device), sized by dfgnn_plan_ints(m):
-//   [0 .. 8)            header: num_fit, num_spill, max_fit_nodes, max_fit_edges, m, nnz, f, budget
-//   [8 .. 8+2m)         fit blocks   (n0, n1) pairs
-//   [8+2m .. 8+4m)      spill chunks (r0, r1) pairs, r1 - r0 <= kHyperRows
-//   [8+4m .. )          scratch: lo[m], hi[m], bounds[m+1]
+//   [0 .. 12)           header: num_fit, num_spill, max_fit_nodes, max_fit_edges, m, nnz, f, budget,
+//                               num_edge_global (fit ranges whose per-edge fp32 array lives in global scratch), 0, 0, 0
+//   [12 .. 12+2m)       fit ranges   (n0, n1 | kPlanEdgeGlobal) pairs
+//   [12+2m .. 12+4m)    spill chunks (r0, r1) pairs, r1 - r0 <= kHyperRows
+//   [12+4m .. )         scratch: lo[m], hi[m], bounds[m+1]
 #include "../../include/dfgnn.h"
 #include "dfgnn_launch.hpp"
 
@@ -44,7 +45,7 @@ __global__ __launch_bounds__(kPlanThreads) void plan_cut_kernel(int m, int nnz, 
                                                                 const int *__restrict__ row_ptr, int *plan) {
   __shared__ int part[kPlanThreads];
   int *hdr = plan;
-  int *fit = plan + 8;
+  int *fit = plan + kPlanHeader;
   int *spill = fit + 2 * (size_t)m;
   int *lo = spill + 2 * (size_t)m;
   int *hi = lo + m;
@@ -97,16 +98,20 @@ __global__ __launch_bounds__(kPlanThreads) void plan_cut_kernel(int m, int nnz, 
   if (t != 0) return;
 
   const int nb = hdr[7];
-  int nfit = 0, nspill = 0, maxn = 0, maxe = 0;
-  auto bytes_of = [&](int n0, int n1) -> long {
-    // resident rows + logits + 1/sum + rebased row_ptr + narrowed column ids (gt_block.hip:carve_block_lds)
+  int nfit = 0, nspill = 0, maxn = 0, maxe = 0, nglobal = 0;
+  // LDS bytes of a range: resident rows + 1/sum + rebased row_ptr + narrowed column ids, plus (bytes_of only)
+  // the per-edge fp32 array (logits / dS).  Layout: dfgnn_block.hpp:carve_block_lds.
+  auto lite_of = [&](int n0, int n1) -> long {
     const long n = n1 - n0, ed = row_ptr[n1] - row_ptr[n0];
-    return n * (long)f * 4 + ed * 4 + n * 8 + ed * (n <= 256 ? 1 : 2);
+    return n * (long)f * 4 + n * 8 + ed * (n <= 256 ? 1 : 2);
   };
+  auto bytes_of = [&](int n0, int n1) -> long { return lite_of(n0, n1) + 4L * (row_ptr[n1] - row_ptr[n0]); };
   auto flush = [&](int n0, int n1) {
     if (n1 <= n0) return;
+    const bool edge_global = bytes_of(n0, n1) > budget_bytes;  // only ever true for an unmerged range
     fit[2 * nfit] = n0;
-    fit[2 * nfit + 1] = n1;
+    fit[2 * nfit + 1] = n1 | (edge_global ? kPlanEdgeGlobal : 0);
+    nglobal += edge_global ? 1 : 0;
     ++nfit;
     maxn = max(maxn, n1 - n0);
     maxe = max(maxe, row_ptr[n1] - row_ptr[n0]);
@@ -114,13 +119,17 @@ __global__ __launch_bounds__(kPlanThreads) void plan_cut_kernel(int m, int nnz, 
   int cur0 = 0, cur1 = 0, prev = 0;
   for (int k = 0; k < nb; ++k) {
     const int end = bounds[k];
-    if (bytes_of(prev, end) > budget_bytes) {           // this closed range alone does not fit
+    if (lite_of(prev, end) > budget_bytes) {            // not even the feature rows of this range fit
       flush(cur0, cur1);
       for (int r = prev; r < end; r += kHyperRows) {
         spill[2 * nspill] = r;
         spill[2 * nspill + 1] = min(end, r + kHyperRows);
         ++nspill;
       }
+      cur0 = cur1 = end;
+    } else if (bytes_of(prev, end) > budget_bytes) {    // rows fit, the per-edge array goes to global scratch
+      flush(cur0, cur1);
+      flush(prev, end);
       cur0 = cur1 = end;
     } else if (cur1 > cur0 && (bytes_of(cur0, end) > budget_bytes || end - cur0 > merge_nodes)) {
       flush(cur0, cur1);
@@ -141,6 +150,8 @@ __global__ __launch_bounds__(kPlanThreads) void plan_cut_kernel(int m, int nnz, 
   hdr[5] = nnz;
   hdr[6] = f;
   hdr[7] = budget_bytes;
+  hdr[8] = nglobal;
+  hdr[9] = hdr[10] = hdr[11] = 0;
 }
 
 }  // namespace dfgnn
@@ -149,23 +160,23 @@ using namespace dfgnn;
 
 extern "C" {
 
-size_t dfgnn_plan_ints(int m) { return m < 0 ? 0 : 8 + 7 * (size_t)m + 1; }
+size_t dfgnn_plan_ints(int m) { return m < 0 ? 0 : kPlanHeader + 7 * (size_t)m + 1; }
 
 int dfgnn_plan_build(int m, int nnz, int f, const int *row_ptr, const int *col_ind, int *plan, int *meta_host,
                      dfgnn_stream_t stream) {
   if (m < 0 || nnz < 0 || f <= 0 || !plan || !meta_host) return kErrBadArg;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  for (int k = 0; k < 8; ++k) meta_host[k] = 0;
+  for (int k = 0; k < kPlanHeader; ++k) meta_host[k] = 0;
   meta_host[4] = m; meta_host[5] = nnz; meta_host[6] = f; meta_host[7] = kBlockLdsBudget;
   if (m == 0) return 0;
   if (!row_ptr || (nnz > 0 && !col_ind)) return kErrBadArg;
-  int *lo = plan + 8 + 4 * (size_t)m;
+  int *lo = plan + kPlanHeader + 4 * (size_t)m;
   int *hi = lo + m;
   plan_row_extent_kernel<<<(m + 255) / 256, 256, 0, s>>>(m, row_ptr, col_ind, lo, hi);
   if (int rc = launch_status()) return rc;
   plan_cut_kernel<<<1, kPlanThreads, 0, s>>>(m, nnz, f, kBlockLdsBudget, kBlockMergeNodes, row_ptr, plan);
   if (int rc = launch_status()) return rc;
-  if (hipError_t rc = hipMemcpyAsync(meta_host, plan, 8 * sizeof(int), hipMemcpyDeviceToHost, s)) return (int)rc;
+  if (hipError_t rc = hipMemcpyAsync(meta_host, plan, kPlanHeader * sizeof(int), hipMemcpyDeviceToHost, s)) return (int)rc;
   return (int)hipStreamSynchronize(s);
 }
 

@@ -16,7 +16,7 @@ _vp, _i, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
 # symbol -> argtypes; mirrors include/dfgnn.h one to one (checked by tests/test_capi_symbols.py)
 SIGNATURES = {
     "dfgnn_plan_build": [_i, _i, _i] + [_vp] * 5,
-    "dfgnn_gt_hyper_fwd": [_i, _i, _i, _i] + [_vp] * 12,
+    "dfgnn_gt_hyper_fwd": [_i, _i, _i, _i] + [_vp] * 13,
     "dfgnn_gt_bwd": [_i, _i, _i, _i] + [_vp] * 19,
     "dfgnn_gt_bwd_rows": [_i, _i, _i, _i] + [_vp] * 11,
     "dfgnn_gt_bwd_cols": [_i, _i, _i, _i] + [_vp] * 11,

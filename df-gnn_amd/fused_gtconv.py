@@ -56,9 +56,10 @@ def gt_hyper_inference(indptr, indices, rows, val, smem_consume, Q, K, V):
     _check_edges(nnz, rows=rows, val=val)
     with torch.cuda.device(Q.device):
         out = torch.empty_like(Q)
-        plan, meta = get_plan(indptr, indices, f, USE_BLOCK_PLAN)
+        plan, meta, need_ws = get_plan(indptr, indices, f, USE_BLOCK_PLAN)
+        ws = torch.empty((h, nnz), dtype=torch.float32, device=Q.device) if need_ws else None
         _n.check(_n.lib().dfgnn_gt_hyper_fwd(m, nnz, h, f, ptr(indptr), ptr(indices), ptr(rows), ptr(val),
-                                             ptr(Q), ptr(K), ptr(V), None, ptr(out), plan, meta,
+                                             ptr(Q), ptr(K), ptr(V), None, ptr(ws), ptr(out), plan, meta,
                                              stream_ptr(Q.device)), "gt_hyper_inference")
     return [out]
 
@@ -82,9 +83,9 @@ def gt_hyper_forward(row_ptr, col_ind, rows, val, col_ptr, row_ind, val_idx, sme
     with torch.cuda.device(Q.device):
         out = torch.empty_like(Q)
         attn_edge = torch.empty((h, nnz), dtype=torch.float32, device=Q.device)
-        plan, meta = get_plan(row_ptr, col_ind, f, USE_BLOCK_PLAN)
+        plan, meta, _ = get_plan(row_ptr, col_ind, f, USE_BLOCK_PLAN)
         _n.check(_n.lib().dfgnn_gt_hyper_fwd(m, nnz, h, f, ptr(row_ptr), ptr(col_ind), ptr(rows), ptr(val),
-                                             ptr(Q), ptr(K), ptr(V), ptr(attn_edge), ptr(out), plan, meta,
+                                             ptr(Q), ptr(K), ptr(V), ptr(attn_edge), None, ptr(out), plan, meta,
                                              stream_ptr(Q.device)), "gt_hyper_forward")
     return [out, attn_edge]
 
@@ -111,7 +112,7 @@ def gt_backward(row_ptr, col_ind, rows, val, col_ptr, row_ind, val_idx, smem_con
     with torch.cuda.device(Q.device):
         grad_edge = torch.empty((h, nnz), dtype=torch.float32, device=Q.device)
         dQ, dK, dV = torch.empty_like(Q), torch.empty_like(K), torch.empty_like(V)
-        plan, meta = get_plan(row_ptr, col_ind, f, USE_BLOCK_PLAN)
+        plan, meta, _ = get_plan(row_ptr, col_ind, f, USE_BLOCK_PLAN)
         _n.check(_n.lib().dfgnn_gt_bwd(m, nnz, h, f, ptr(row_ptr), ptr(col_ind), ptr(rows), ptr(val),
                                        ptr(col_ptr), ptr(row_ind), ptr(val_idx), ptr(Q), ptr(K), ptr(V),
                                        ptr(attn_edge), ptr(grad), ptr(grad_edge), ptr(dQ), ptr(dK), ptr(dV),

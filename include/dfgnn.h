@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define DFGNN_ABI_VERSION 2
+#define DFGNN_ABI_VERSION 3
 
 #define DFGNN_E_BADARG (-1)      /* negative size / NULL required pointer                      */
 #define DFGNN_E_UNSUPPORTED (-2) /* feature width outside the compiled range (f > 1024, or     */
@@ -53,9 +53,9 @@ const char *dfgnn_error_string(int code);
  * without a plan.  The plan depends on the graph structure and on f only; build it once per batch
  * (it belongs to preprocessing, like the reference's preprocess_Hyper, DFGNN/layers/util.py:82-100).
  *   plan       device buffer of dfgnn_plan_ints(m) int32
- *   meta_host  host buffer of 8 int32 filled on return: num_fit, num_spill, max_fit_nodes,
- *              max_fit_edges, m, nnz, f, lds_budget
- * dfgnn_plan_build synchronises `stream` (it copies the 8 header words back); nothing else in this
+ *   meta_host  host buffer of 12 int32 filled on return: num_fit, num_spill, max_fit_nodes,
+ *              max_fit_edges, m, nnz, f, lds_budget, num_edge_global, 0, 0, 0
+ * dfgnn_plan_build synchronises `stream` (it copies the 12 header words back); nothing else in this
  * library does. */
 size_t dfgnn_plan_ints(int m);
 int dfgnn_plan_build(int m, int nnz, int f, const int *row_ptr, const int *col_ind, int *plan,
@@ -66,11 +66,13 @@ int dfgnn_plan_build(int m, int nnz, int f, const int *row_ptr, const int *col_i
  *                               fused_gtconv_hyper.cu:679-725) when attn_edge == NULL, and
  *          gt_hyper_forward    (fused_gtconv.cpp:79-116, fused_gtconv_hyper.cu:727-760)
  *          when attn_edge != NULL (training forward: also writes the normalised attention).
- * plan / plan_meta: device plan + its 8 host header words from dfgnn_plan_build, or NULL/NULL. */
+ * plan / plan_meta: device plan + its 12 host header words from dfgnn_plan_build, or NULL/NULL.
+ * edge_ws: scratch fp32[h, nnz], needed only for inference (attn_edge == NULL) with a plan whose
+ *          meta[8] > 0 (ranges whose per-edge values do not fit LDS next to their rows); else NULL. */
 int dfgnn_gt_hyper_fwd(int m, int nnz, int h, int f, const int *row_ptr, const int *col_ind,
                        const int *rows, const float *val, const float *Q, const float *K,
-                       const float *V, float *attn_edge, float *out, const int *plan,
-                       const int *plan_meta, dfgnn_stream_t stream);
+                       const float *V, float *attn_edge, float *edge_ws, float *out,
+                       const int *plan, const int *plan_meta, dfgnn_stream_t stream);
 
 /* replaces gt_backward (fused_gtconv.cpp:125-172, fused_gtconv_backward.cu:193-265).
  * col_ptr int32[m+1], row_ind int32[nnz], val_idx int32[nnz] (CSR slot of each CSC entry).

@@ -304,7 +304,7 @@ def test_block_plan_structure():
     nfit, nspill, maxn, maxe = plan.meta[:4]
     buf = plan.buf.cpu().numpy()
     m = g.num_nodes()
-    fit = buf[8:8 + 2 * nfit].reshape(-1, 2)
+    fit = buf[12:12 + 2 * nfit].reshape(-1, 2)
     ends = _natural_ranges(row_ptr.cpu().numpy(), col_ind.cpu().numpy())
     assert nspill == 0 and nfit >= 1
     assert fit[0, 0] == 0 and fit[-1, 1] == m and (fit[1:, 0] == fit[:-1, 1]).all()      # a partition of the rows
@@ -315,7 +315,7 @@ def test_block_plan_structure():
     assert maxe == (rp[fit[:, 1]] - rp[fit[:, 0]]).max()
     # f = 16: many graphs merge into one block of <= 256 nodes
     plan16 = build_plan(row_ptr, col_ind, 16)
-    fit16 = plan16.buf.cpu().numpy()[8:8 + 2 * plan16.meta[0]].reshape(-1, 2)
+    fit16 = plan16.buf.cpu().numpy()[12:12 + 2 * plan16.meta[0]].reshape(-1, 2)
     assert plan16.meta[0] < nfit and (fit16[:, 1] - fit16[:, 0]).max() <= 256
     # a full graph is one closed range that cannot fit: everything spills in <= 16-row chunks
     c = S.cora_like()
@@ -381,13 +381,19 @@ def test_block_plan_mixed_fit_and_spill(oracle_mod):
     keep = rng.random(len(iu)) < 0.05
     big = Graph(np.concatenate([iu[keep], ju[keep]]), np.concatenate([ju[keep], iu[keep]]), big_n)
     lonely = Graph(np.zeros(0, np.int64), np.zeros(0, np.int64), 5)
-    g = batch([S.pattern_like(batch_size=3, seed=1), big, lonely, S.pattern_like(batch_size=2, seed=2)]).to(DEV)
+    # 180 nodes at 55 % density: its K/V rows fit LDS but its per-edge array does not -> "edge-global" range
+    iu, ju = np.triu_indices(180, k=1)
+    keep = rng.random(len(iu)) < 0.55
+    dense = Graph(np.concatenate([iu[keep], ju[keep]]), np.concatenate([ju[keep], iu[keep]]), 180)
+    g = batch([S.pattern_like(batch_size=3, seed=1), big, lonely, dense, S.pattern_like(batch_size=2, seed=2)]).to(DEV)
     A, rows, row_ptr, col_ind, val, col_ptr, row_ind, val_idx, smem = preprocess_Hyper_fw_bw(g)
     m = g.num_nodes()
     Q, K, V = S.gt_features(m, 1, 128, seed=8, device=DEV)
     out, attn = gt.gt_hyper_forward(row_ptr, col_ind, rows, val, col_ptr, row_ind, val_idx, smem, Q, K, V)
     plan = row_ptr._dfgnn_plans[128]
-    assert plan.num_fit >= 2 and plan.num_spill == (big_n + 15) // 16
+    assert plan.num_fit >= 3 and plan.num_spill == (big_n + 15) // 16 and plan.num_edge_global == 1
+    inf = gt.gt_hyper_inference(row_ptr, col_ind, rows, val, smem, Q, K, V)[0]   # inference path needs the scratch
+    assert torch.allclose(inf, out, atol=1e-6)
     n = lambda t: t.cpu().numpy()  # noqa: E731
     want, want_attn = oracle_mod.gt_forward(n(row_ptr), n(col_ind), n(val), n(Q), n(K), n(V), want_attn=True)
     _close(out, want, "mixed fit/spill out")
