@@ -95,63 +95,127 @@ __global__ __launch_bounds__(kPlanThreads) void plan_cut_kernel(int m, int nnz, 
   for (int i = b; i < e; ++i)
     if (hi[i] <= i && (i + 1 == m || lo[i + 1] >= i + 1)) bounds[pos++] = i + 1;
   __syncthreads();
-  if (t != 0) return;
 
+  // Greedy merge by thread 0.  The ends of the natural ranges and their row_ptr values are first copied to
+  // LDS (when there are few enough) so the serial walk does not pay a global-memory round trip per range.
+  constexpr int kCache = 4096;
+  __shared__ int s_end[kCache], s_rp[kCache];
+  __shared__ int s_nfit;
   const int nb = hdr[7];
-  int nfit = 0, nspill = 0, maxn = 0, maxe = 0, nglobal = 0;
-  // LDS bytes of a range: resident rows + 1/sum + rebased row_ptr + narrowed column ids, plus (bytes_of only)
-  // the per-edge fp32 array (logits / dS).  Layout: dfgnn_block.hpp:carve_block_lds.
-  auto lite_of = [&](int n0, int n1) -> long {
-    const long n = n1 - n0, ed = row_ptr[n1] - row_ptr[n0];
-    return n * (long)f * 4 + n * 8 + ed * (n <= 256 ? 1 : 2);
-  };
-  auto bytes_of = [&](int n0, int n1) -> long { return lite_of(n0, n1) + 4L * (row_ptr[n1] - row_ptr[n0]); };
-  auto flush = [&](int n0, int n1) {
-    if (n1 <= n0) return;
-    const bool edge_global = bytes_of(n0, n1) > budget_bytes;  // only ever true for an unmerged range
-    fit[2 * nfit] = n0;
-    fit[2 * nfit + 1] = n1 | (edge_global ? kPlanEdgeGlobal : 0);
-    nglobal += edge_global ? 1 : 0;
-    ++nfit;
-    maxn = max(maxn, n1 - n0);
-    maxe = max(maxe, row_ptr[n1] - row_ptr[n0]);
-  };
-  int cur0 = 0, cur1 = 0, prev = 0;
-  for (int k = 0; k < nb; ++k) {
-    const int end = bounds[k];
-    if (lite_of(prev, end) > budget_bytes) {            // not even the feature rows of this range fit
-      flush(cur0, cur1);
-      for (int r = prev; r < end; r += kHyperRows) {
-        spill[2 * nspill] = r;
-        spill[2 * nspill + 1] = min(end, r + kHyperRows);
-        ++nspill;
-      }
-      cur0 = cur1 = end;
-    } else if (bytes_of(prev, end) > budget_bytes) {    // rows fit, the per-edge array goes to global scratch
-      flush(cur0, cur1);
-      flush(prev, end);
-      cur0 = cur1 = end;
-    } else if (cur1 > cur0 && (bytes_of(cur0, end) > budget_bytes || end - cur0 > merge_nodes)) {
-      flush(cur0, cur1);
-      cur0 = prev;
-      cur1 = end;
-    } else {
-      if (cur1 == cur0) cur0 = prev;
-      cur1 = end;
+  const bool cached = nb <= kCache;
+  if (cached)
+    for (int k = t; k < nb; k += kPlanThreads) {
+      const int en = bounds[k];
+      s_end[k] = en;
+      s_rp[k] = row_ptr[en];
     }
-    prev = end;
+  __syncthreads();
+  if (t == 0) {
+    int nfit = 0, nspill = 0, maxn = 0, maxe = 0, nglobal = 0;
+    // LDS bytes of a range [n0, n1) holding ed edges: resident rows + 1/sum + rebased row_ptr + narrowed
+    // column ids, plus (full only) the per-edge fp32 array.  Layout: dfgnn_block.hpp:carve_block_lds.
+    auto lite = [&](long n, long ed) -> long { return n * (long)f * 4 + n * 8 + ed * (n <= 256 ? 1 : 2); };
+    auto full = [&](long n, long ed) -> long { return lite(n, ed) + 4 * ed; };
+    auto flush = [&](int n0, int n1, int ed) {
+      if (n1 <= n0) return;
+      const bool edge_global = full(n1 - n0, ed) > budget_bytes;  // only ever true for an unmerged range
+      fit[2 * nfit] = n0;
+      fit[2 * nfit + 1] = n1 | (edge_global ? kPlanEdgeGlobal : 0);
+      nglobal += edge_global ? 1 : 0;
+      ++nfit;
+      maxn = max(maxn, n1 - n0);
+      maxe = max(maxe, ed);
+    };
+    int cur0 = 0, cur1 = 0, prev = 0;          // current merged range [cur0, cur1), previous range end
+    int rp_cur0 = row_ptr[0], rp_cur1 = rp_cur0, rp_prev = rp_cur0;
+    for (int k = 0; k < nb; ++k) {
+      const int end = cached ? s_end[k] : bounds[k];
+      const int rp_end = cached ? s_rp[k] : row_ptr[end];
+      const long n_one = end - prev, e_one = rp_end - rp_prev;
+      if (lite(n_one, e_one) > budget_bytes) {            // not even the feature rows of this range fit
+        flush(cur0, cur1, rp_cur1 - rp_cur0);
+        for (int r = prev; r < end; r += kHyperRows) {
+          spill[2 * nspill] = r;
+          spill[2 * nspill + 1] = min(end, r + kHyperRows);
+          ++nspill;
+        }
+        cur0 = cur1 = end;
+        rp_cur0 = rp_cur1 = rp_end;
+      } else if (full(n_one, e_one) > budget_bytes) {     // rows fit, the per-edge array goes to global scratch
+        flush(cur0, cur1, rp_cur1 - rp_cur0);
+        flush(prev, end, (int)e_one);
+        cur0 = cur1 = end;
+        rp_cur0 = rp_cur1 = rp_end;
+      } else if (cur1 > cur0 && (full(end - cur0, rp_end - rp_cur0) > budget_bytes || end - cur0 > merge_nodes)) {
+        flush(cur0, cur1, rp_cur1 - rp_cur0);
+        cur0 = prev;
+        rp_cur0 = rp_prev;
+        cur1 = end;
+        rp_cur1 = rp_end;
+      } else {
+        if (cur1 == cur0) { cur0 = prev; rp_cur0 = rp_prev; }
+        cur1 = end;
+        rp_cur1 = rp_end;
+      }
+      prev = end;
+      rp_prev = rp_end;
+    }
+    flush(cur0, cur1, rp_cur1 - rp_cur0);
+    hdr[0] = nfit;
+    hdr[1] = nspill;
+    hdr[2] = maxn;
+    hdr[3] = maxe;
+    hdr[4] = m;
+    hdr[5] = nnz;
+    hdr[6] = f;
+    hdr[7] = budget_bytes;
+    hdr[8] = nglobal;
+    hdr[9] = hdr[10] = hdr[11] = 0;
+    s_nfit = nfit;
   }
-  flush(cur0, cur1);
-  hdr[0] = nfit;
-  hdr[1] = nspill;
-  hdr[2] = maxn;
-  hdr[3] = maxe;
-  hdr[4] = m;
-  hdr[5] = nnz;
-  hdr[6] = f;
-  hdr[7] = budget_bytes;
-  hdr[8] = nglobal;
-  hdr[9] = hdr[10] = hdr[11] = 0;
+  __syncthreads();
+
+  // Largest ranges first (workgroups are dispatched in index order, so the tail of the launch is made of the
+  // shortest ones): bitonic sort of (edges, index) in LDS, reusing s_end / s_rp.  Skipped for long lists,
+  // where the tail is negligible anyway.
+  const int nfit = s_nfit;
+  if (nfit > 1 && nfit <= kCache) {
+    int N = 1;
+    while (N < nfit) N <<= 1;
+    for (int i = t; i < N; i += kPlanThreads) {
+      if (i < nfit) {
+        const int n0 = fit[2 * i], n1 = fit[2 * i + 1] & ~kPlanEdgeGlobal;
+        s_end[i] = row_ptr[n1] - row_ptr[n0];
+      } else {
+        s_end[i] = -1;
+      }
+      s_rp[i] = i;
+    }
+    __syncthreads();
+    for (int k = 2; k <= N; k <<= 1)
+      for (int j = k >> 1; j > 0; j >>= 1) {
+        for (int i = t; i < N; i += kPlanThreads) {
+          const int x = i ^ j;
+          if (x > i) {
+            const bool desc = (i & k) == 0;
+            const int a = s_end[i], c = s_end[x];
+            if ((a < c) == desc && a != c) {
+              s_end[i] = c; s_end[x] = a;
+              const int ia = s_rp[i]; s_rp[i] = s_rp[x]; s_rp[x] = ia;
+            }
+          }
+        }
+        __syncthreads();
+      }
+    int *tmp = lo;  // lo[] and hi[] (2m ints) are free now
+    for (int i = t; i < nfit; i += kPlanThreads) {
+      const int src = s_rp[i];
+      tmp[2 * i] = fit[2 * src];
+      tmp[2 * i + 1] = fit[2 * src + 1];
+    }
+    __syncthreads();
+    for (int i = t; i < 2 * nfit; i += kPlanThreads) fit[i] = tmp[i];
+  }
 }
 
 }  // namespace dfgnn

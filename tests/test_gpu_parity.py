@@ -304,18 +304,21 @@ def test_block_plan_structure():
     nfit, nspill, maxn, maxe = plan.meta[:4]
     buf = plan.buf.cpu().numpy()
     m = g.num_nodes()
-    fit = buf[12:12 + 2 * nfit].reshape(-1, 2)
+    fit = buf[12:12 + 2 * nfit].reshape(-1, 2) & ~(1 << 30)
+    rp = row_ptr.cpu().numpy()
+    edges_in_order = rp[fit[:, 1]] - rp[fit[:, 0]]
+    assert (np.diff(edges_in_order) <= 0).all()                                          # largest ranges first
+    fit = fit[np.argsort(fit[:, 0])]
     ends = _natural_ranges(row_ptr.cpu().numpy(), col_ind.cpu().numpy())
     assert nspill == 0 and nfit >= 1
     assert fit[0, 0] == 0 and fit[-1, 1] == m and (fit[1:, 0] == fit[:-1, 1]).all()      # a partition of the rows
     assert set(fit[:, 1]).issubset(set(ends))                                            # cuts only at closed ranges
     assert set(np.cumsum(sizes)).issuperset(set(fit[:, 1]))                              # = graph boundaries
     assert maxn == (fit[:, 1] - fit[:, 0]).max() and maxn <= 256
-    rp = row_ptr.cpu().numpy()
     assert maxe == (rp[fit[:, 1]] - rp[fit[:, 0]]).max()
     # f = 16: many graphs merge into one block of <= 256 nodes
     plan16 = build_plan(row_ptr, col_ind, 16)
-    fit16 = plan16.buf.cpu().numpy()[12:12 + 2 * plan16.meta[0]].reshape(-1, 2)
+    fit16 = plan16.buf.cpu().numpy()[12:12 + 2 * plan16.meta[0]].reshape(-1, 2) & ~(1 << 30)
     assert plan16.meta[0] < nfit and (fit16[:, 1] - fit16[:, 0]).max() <= 256
     # a full graph is one closed range that cannot fit: everything spills in <= 16-row chunks
     c = S.cora_like()
