@@ -156,8 +156,19 @@ def main():
     abytes = algorithmic_bytes(m, nnz, h, f)
     dom = max(("gt_hyper_fwd", "gt_bwd"), key=kernel_us.get)  # the launches the timed step actually runs
     achieved = abytes[dom] / (kernel_us[dom] * 1e-6) / 1e9
+    # HBM bytes per launch from PMC counters (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc passes on this
+    # exact workload; profiles/r01_pmc_block_kernels.json).  bench.py cannot collect counters itself, so the figure
+    # is reported only when the workload matches the profiled one, else null.
+    traffic = None
+    try:
+        prof = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_block_kernels.json")))
+        if f"m={m}, nnz={nnz}" in prof["workload"] and h == 1 and f == 128:
+            key = {"gt_hyper_fwd": "gt_block_fwd_kernel", "gt_bwd": "gt_block_bwd_kernel"}[dom]
+            traffic = int(prof["traffic"][key]["total_bytes"])
+    except Exception:
+        traffic = None
     roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "algorithmic_bytes": abytes[dom], "avg_us": round(kernel_us[dom], 2),
                 "all_kernels": {k: {"avg_us": round(v, 2), "algorithmic_bytes": abytes[k],
                                     "achieved_GBs": round(abytes[k] / (v * 1e-6) / 1e9, 1)}

@@ -15,6 +15,10 @@ inline bool make_plan(Plan &p, const int *plan_dev, const int *meta, int m, int 
   if (!plan_dev || !meta) return false;
   if (meta[4] != m || meta[5] != nnz || meta[6] != f || meta[7] != kBlockLdsBudget) return false;
   if (meta[0] <= 0) return false;
+  // Low-degree batches (e.g. molecule / peptide graphs, ~2 edges per row) are bound by the node features, not
+  // by the per-edge gathers: a 1024-thread workgroup per range only adds fixed cost there (measured on the
+  // Peptides-like config: 279 us resident vs 180 us general for fwd+bwd), so such graphs keep the general kernels.
+  if ((long)nnz < (long)kBlockMinAvgDegree * m) return false;
   p = Plan{plan_dev, meta[0], meta[1], meta[2], meta[3], m, nnz, f, meta[8]};
   return true;
 }

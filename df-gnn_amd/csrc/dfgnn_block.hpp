@@ -103,34 +103,36 @@ __device__ __forceinline__ void load_resident(float *res, const float *__restric
 
 // Logits of one <= 64-edge chunk of a row: group gid handles the chunk's edges gid, gid+EPW, ... (their
 // block-local columns were staged de-interleaved in sci); on return lane (gid, gl) holds the logit of
-// edge gl*EPW + gid of the chunk.  Four iterations (4*EPW edges) per trip keep 4*NCH LDS reads in flight.
+// edge gl*EPW + gid of the chunk.  TRIP iterations (TRIP*EPW edges, TRIP*NCH LDS row reads in flight) per
+// trip; slots past the chunk hold column 0, so surplus iterations of the last trip read a valid row.
 template <class C>
 __device__ __forceinline__ float block_chunk_logits(const float *res, const int *sci, const Frag<C> &q, int nt,
                                                     int gid, int gl) {
   constexpr int G = C::G, EPW = C::EPW, F = C::G * C::VEC * C::NCH;
+  constexpr int TRIP = 4;  // 8 measured slower on C3 (more surplus slots, 116 VGPRs)
   const int iters = (nt + EPW - 1) / EPW;
   float mine = 0.f;
-  for (int it = 0; it < iters; it += 4) {
-    const int4 c4 = *reinterpret_cast<const int4 *>(sci + gid * G + it);  // slots past the chunk hold col 0
-    Frag<C> k0, k1, k2, k3;
-    frag_load_full<C>(k0, res + c4.x * F, gl);
-    frag_load_full<C>(k1, res + c4.y * F, gl);
-    frag_load_full<C>(k2, res + c4.z * F, gl);
-    frag_load_full<C>(k3, res + c4.w * F, gl);
-    float d0 = lanes_sum<G>(frag_dot_pk<C>(q, k0));
-    float d1 = lanes_sum<G>(frag_dot_pk<C>(q, k1));
-    float d2 = lanes_sum<G>(frag_dot_pk<C>(q, k2));
-    float d3 = lanes_sum<G>(frag_dot_pk<C>(q, k3));
-    asm volatile("" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3));  // keep the selects below as v_cndmask
+  for (int it = 0; it < iters; it += TRIP) {
+    int c[TRIP];
+#pragma unroll
+    for (int u = 0; u < TRIP; u += 4) {
+      const int4 c4 = *reinterpret_cast<const int4 *>(sci + gid * G + it + u);
+      c[u] = c4.x; c[u + 1] = c4.y; c[u + 2] = c4.z; c[u + 3] = c4.w;
+    }
+    Frag<C> k[TRIP];
+#pragma unroll
+    for (int u = 0; u < TRIP; ++u) frag_load_full<C>(k[u], res + c[u] * F, gl);
+    float d[TRIP];
+#pragma unroll
+    for (int u = 0; u < TRIP; ++u) d[u] = lanes_sum<G>(frag_dot_pk<C>(q, k[u]));
+#pragma unroll
+    for (int u = 0; u < TRIP; ++u) asm volatile("" : "+v"(d[u]));  // keep the selects below as v_cndmask
     const int rel = gl - it;
-    mine = rel == 0 ? d0 : mine;
-    mine = rel == 1 ? d1 : mine;
-    mine = rel == 2 ? d2 : mine;
-    mine = rel == 3 ? d3 : mine;
+#pragma unroll
+    for (int u = 0; u < TRIP; ++u) mine = (rel == u) ? d[u] : mine;
   }
   return mine;
 }
-
 
 // acc += sum_{k<deg} w_k * res[row_k]: the entries of one CSR row (or CSC column) are produced by
 // `entry(k, row, w)` on lane k % 64 of each 64-entry chunk, staged de-interleaved in the wave's scratch and
@@ -148,18 +150,20 @@ __device__ __forceinline__ void block_spmm(Frag<C> &acc, const float *res, int2 
     sc[stage] = make_int2(row * F, __float_as_int(w));
     wave_sync();
     const int iters = (nt + EPW - 1) / EPW;
-    for (int it = 0; it < iters; it += 4) {
-      const int4 a = *reinterpret_cast<const int4 *>(sc + gid * G + it);       // (row offset, w) x 2
-      const int4 b = *reinterpret_cast<const int4 *>(sc + gid * G + it + 2);   // (row offset, w) x 2
-      Frag<C> v0, v1, v2, v3;
-      frag_load_full<C>(v0, res + a.x, gl);
-      frag_load_full<C>(v1, res + a.z, gl);
-      frag_load_full<C>(v2, res + b.x, gl);
-      frag_load_full<C>(v3, res + b.z, gl);
-      frag_fma_pk<C>(acc, __int_as_float(a.y), v0);
-      frag_fma_pk<C>(acc, __int_as_float(a.w), v1);
-      frag_fma_pk<C>(acc, __int_as_float(b.y), v2);
-      frag_fma_pk<C>(acc, __int_as_float(b.w), v3);
+    constexpr int TRIP = 4;
+    for (int it = 0; it < iters; it += TRIP) {
+      int ro[TRIP];
+      float wv[TRIP];
+#pragma unroll
+      for (int u = 0; u < TRIP; u += 2) {
+        const int4 a = *reinterpret_cast<const int4 *>(sc + gid * G + it + u);  // (row offset, w) x 2
+        ro[u] = a.x; wv[u] = __int_as_float(a.y); ro[u + 1] = a.z; wv[u + 1] = __int_as_float(a.w);
+      }
+      Frag<C> v[TRIP];
+#pragma unroll
+      for (int u = 0; u < TRIP; ++u) frag_load_full<C>(v[u], res + ro[u], gl);
+#pragma unroll
+      for (int u = 0; u < TRIP; ++u) frag_fma_pk<C>(acc, wv[u], v[u]);
     }
     wave_sync();
   }

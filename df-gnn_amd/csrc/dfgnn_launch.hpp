@@ -33,6 +33,7 @@ constexpr int kBlockWaves = kBlockThreads / kWave;
 constexpr int kBlockScratchBytes = kBlockWaves * kWave * 8;  // per-wave (col, weight) staging, 512 B each
 constexpr int kLdsBytes = 160 * 1024;
 constexpr int kBlockLdsBudget = kLdsBytes - kBlockScratchBytes - 256;  // resident rows + edge values + 1/sum
+constexpr int kBlockMinAvgDegree = 8;                    // below this average degree the general kernels win
 constexpr int kBlockMergeNodes = 256;                    // small graphs are merged up to this many nodes
 
 constexpr int kPlanHeader = 12;                          // int32 header words of a plan buffer
