@@ -120,11 +120,24 @@ __device__ __forceinline__ float block_chunk_logits(const float *res, const int 
       c[u] = c4.x; c[u + 1] = c4.y; c[u + 2] = c4.z; c[u + 3] = c4.w;
     }
     Frag<C> k[TRIP];
+#if defined(DFGNN_ABL) && DFGNN_ABL == 2   // ablation (diagnostic builds only): no LDS row reads
+#pragma unroll
+    for (int u = 0; u < TRIP; ++u) { k[u] = q; k[u].v[0][0] += (float)c[u]; }
+#else
 #pragma unroll
     for (int u = 0; u < TRIP; ++u) frag_load_full<C>(k[u], res + c[u] * F, gl);
+#endif
     float d[TRIP];
+#if defined(DFGNN_ABL) && DFGNN_ABL == 1   // ablation: no cross-lane reduction
+#pragma unroll
+    for (int u = 0; u < TRIP; ++u) d[u] = frag_dot_pk<C>(q, k[u]);
+#elif defined(DFGNN_ABL) && DFGNN_ABL == 3  // ablation: no FMAs
+#pragma unroll
+    for (int u = 0; u < TRIP; ++u) d[u] = lanes_sum<G>(k[u].v[0][0] + k[u].v[C::NCH - 1][3]);
+#else
 #pragma unroll
     for (int u = 0; u < TRIP; ++u) d[u] = lanes_sum<G>(frag_dot_pk<C>(q, k[u]));
+#endif
 #pragma unroll
     for (int u = 0; u < TRIP; ++u) asm volatile("" : "+v"(d[u]));  // keep the selects below as v_cndmask
     const int rel = gl - it;

@@ -6,7 +6,7 @@ for p in (ROOT, os.path.join(ROOT, "df-gnn_amd")):
     sys.path.insert(0, p)
 import numpy as np, torch
 import dfgnn_native
-dfgnn_native.LIB_PATH = os.path.join(ROOT, "df-gnn_amd", "libdfgnn_stamps.so")
+dfgnn_native.LIB_PATH = os.path.join(ROOT, "df-gnn_amd", os.environ.get("DFGNN_STAMP_LIB", "libdfgnn_stamps.so"))
 import fused_gtconv as gt
 from DFGNN.layers import preprocess_Hyper_fw_bw
 from DFGNN.utils import synthetic as S
