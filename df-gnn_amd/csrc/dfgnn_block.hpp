@@ -101,50 +101,74 @@ __device__ __forceinline__ void load_resident(float *res, const float *__restric
   }
 }
 
+// Which edge of a 64-edge chunk lane (gid, gl) ends up holding after block_chunk_logits.
+template <class C>
+__device__ __forceinline__ int chunk_edge_of_lane(int gid, int gl) {
+  if constexpr (C::G == 16) return (4 * (gl & 3) + (gl >> 2)) * C::EPW + gid;  // reduce-scatter layout
+  return gl * C::EPW + gid;
+}
+
 // Logits of one <= 64-edge chunk of a row: group gid handles the chunk's edges gid, gid+EPW, ... (their
 // block-local columns were staged de-interleaved in sci); on return lane (gid, gl) holds the logit of
-// edge gl*EPW + gid of the chunk.  TRIP iterations (TRIP*EPW edges, TRIP*NCH LDS row reads in flight) per
-// trip; slots past the chunk hold column 0, so surplus iterations of the last trip read a valid row.
+// edge chunk_edge_of_lane(gid, gl) of the chunk.  Four iterations (4*EPW edges, 4*NCH LDS row reads in
+// flight) per trip; slots past the chunk hold column 0, so surplus iterations read a valid row.
+// G == 16: the four partial dot products of a trip are reduce-scattered over the 16 lanes (row_mirror,
+// row_half_mirror, two quad swaps: 11 VALU ops, quad j ends with the total of iteration it + j) instead of
+// four all-reduces (16 ops + 4 selects).
 template <class C>
 __device__ __forceinline__ float block_chunk_logits(const float *res, const int *sci, const Frag<C> &q, int nt,
                                                     int gid, int gl) {
   constexpr int G = C::G, EPW = C::EPW, F = C::G * C::VEC * C::NCH;
-  constexpr int TRIP = 4;  // 8 measured slower on C3 (more surplus slots, 116 VGPRs)
   const int iters = (nt + EPW - 1) / EPW;
   float mine = 0.f;
-  for (int it = 0; it < iters; it += TRIP) {
-    int c[TRIP];
-#pragma unroll
-    for (int u = 0; u < TRIP; u += 4) {
-      const int4 c4 = *reinterpret_cast<const int4 *>(sci + gid * G + it + u);
-      c[u] = c4.x; c[u + 1] = c4.y; c[u + 2] = c4.z; c[u + 3] = c4.w;
+  const bool upper = (gl & 8) != 0, odd4 = (gl & 4) != 0;
+  for (int it = 0; it < iters; it += 4) {
+    const int4 c4 = *reinterpret_cast<const int4 *>(sci + gid * G + it);
+    Frag<C> k0, k1, k2, k3;
+    frag_load_full<C>(k0, res + c4.x * F, gl);
+    frag_load_full<C>(k1, res + c4.y * F, gl);
+    frag_load_full<C>(k2, res + c4.z * F, gl);
+    frag_load_full<C>(k3, res + c4.w * F, gl);
+    float d0 = frag_dot_pk<C>(q, k0), d1 = frag_dot_pk<C>(q, k1), d2 = frag_dot_pk<C>(q, k2),
+          d3 = frag_dot_pk<C>(q, k3);
+    if constexpr (G == 16) {
+      const float x0 = (upper ? d2 : d0) + dpp_perm<kDppMirror>(upper ? d0 : d2);
+      const float x1 = (upper ? d3 : d1) + dpp_perm<kDppMirror>(upper ? d1 : d3);
+      float y = (odd4 ? x1 : x0) + dpp_perm<kDppHalfMirror>(odd4 ? x0 : x1);
+      y += dpp_perm<kDppXor2>(y);
+      y += dpp_perm<kDppXor1>(y);
+      asm volatile("" : "+v"(y));  // keep the select below a v_cndmask
+      mine = ((gl & 3) == (it >> 2)) ? y : mine;
+    } else {
+      d0 = lanes_sum<G>(d0);
+      d1 = lanes_sum<G>(d1);
+      d2 = lanes_sum<G>(d2);
+      d3 = lanes_sum<G>(d3);
+      asm volatile("" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3));  // keep the selects below as v_cndmask
+      const int rel = gl - it;
+      mine = rel == 0 ? d0 : mine;
+      mine = rel == 1 ? d1 : mine;
+      mine = rel == 2 ? d2 : mine;
+      mine = rel == 3 ? d3 : mine;
     }
-    Frag<C> k[TRIP];
-#if defined(DFGNN_ABL) && DFGNN_ABL == 2   // ablation (diagnostic builds only): no LDS row reads
-#pragma unroll
-    for (int u = 0; u < TRIP; ++u) { k[u] = q; k[u].v[0][0] += (float)c[u]; }
-#else
-#pragma unroll
-    for (int u = 0; u < TRIP; ++u) frag_load_full<C>(k[u], res + c[u] * F, gl);
-#endif
-    float d[TRIP];
-#if defined(DFGNN_ABL) && DFGNN_ABL == 1   // ablation: no cross-lane reduction
-#pragma unroll
-    for (int u = 0; u < TRIP; ++u) d[u] = frag_dot_pk<C>(q, k[u]);
-#elif defined(DFGNN_ABL) && DFGNN_ABL == 3  // ablation: no FMAs
-#pragma unroll
-    for (int u = 0; u < TRIP; ++u) d[u] = lanes_sum<G>(k[u].v[0][0] + k[u].v[C::NCH - 1][3]);
-#else
-#pragma unroll
-    for (int u = 0; u < TRIP; ++u) d[u] = lanes_sum<G>(frag_dot_pk<C>(q, k[u]));
-#endif
-#pragma unroll
-    for (int u = 0; u < TRIP; ++u) asm volatile("" : "+v"(d[u]));  // keep the selects below as v_cndmask
-    const int rel = gl - it;
-#pragma unroll
-    for (int u = 0; u < TRIP; ++u) mine = (rel == u) ? d[u] : mine;
   }
   return mine;
+}
+
+// out_row = scale * (sum of the wave's per-group partial rows): the epilogue of every SpMM pass.
+template <class C>
+__device__ __forceinline__ void block_store_row(Frag<C> &acc, float scale, float *__restrict__ out_row, int gid,
+                                                int gl) {
+  if constexpr (C::G == 16) {
+    float t[C::NCH];
+    frag_reduce_groups_swap<C>(acc, t);
+    const int comp = group_sum_comp(gid);
+#pragma unroll
+    for (int ch = 0; ch < C::NCH; ++ch) out_row[(ch * 16 + gl) * 4 + comp] = t[ch] * scale;
+  } else {
+    frag_reduce_groups<C>(acc);
+    if (gid == 0) frag_store_full<C>(acc, scale, out_row, gl);
+  }
 }
 
 // acc += sum_{k<deg} w_k * res[row_k]: the entries of one CSR row (or CSC column) are produced by

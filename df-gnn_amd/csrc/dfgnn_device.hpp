@@ -210,6 +210,34 @@ __device__ __forceinline__ void frag_scale(Frag<C> &acc, float s) {
     for (int k = 0; k < C::VEC; ++k) acc.v[ch][k] *= s;
 }
 
+// v_permlane{32,16}_swap_b32 through inline asm (hipcc 7.2 mis-selects the second result of the builtin).
+// swap32: lanes 32-63 of a <-> lanes 0-31 of b.  swap16: odd 16-lane rows of a <-> even rows of b.
+__device__ __forceinline__ void permlane32_swap(float &a, float &b) {
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ void permlane16_swap(float &a, float &b) {
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+}
+
+// Sum the four per-group partial rows of a wave (G == 16) with 3 swaps + 3 adds per float4 chunk instead of
+// 8 ds_bpermute + 8 adds.  On return t[ch] of lane (row r, gl) holds the total of component kGroupSumComp[r]
+// of chunk ch at lane position gl, i.e. float (ch*16 + gl)*4 + kGroupSumComp[r] of the feature row.
+template <class C>
+__device__ __forceinline__ void frag_reduce_groups_swap(Frag<C> &acc, float (&t)[C::NCH]) {
+  static_assert(C::G == 16 && C::VEC == 4, "swap reduction is for the 16-lane row layout");
+#pragma unroll
+  for (int ch = 0; ch < C::NCH; ++ch) {
+    float r0 = acc.v[ch][0], r1 = acc.v[ch][1], r2 = acc.v[ch][2], r3 = acc.v[ch][3];
+    permlane32_swap(r0, r1);   // r0 = [r0.lo32, r1.lo32], r1 = [r0.hi32, r1.hi32]
+    permlane32_swap(r2, r3);
+    float s0 = r0 + r1;        // rows 0,1: comp 0 (rows 0+2, 1+3); rows 2,3: comp 1
+    float s1 = r2 + r3;        // rows 0,1: comp 2;                 rows 2,3: comp 3
+    permlane16_swap(s0, s1);   // s0 = [s0.r0, s1.r0, s0.r2, s1.r2], s1 = [s0.r1, s1.r1, s0.r3, s1.r3]
+    t[ch] = s0 + s1;           // row 0: comp 0, row 1: comp 2, row 2: comp 1, row 3: comp 3
+  }
+}
+__device__ __forceinline__ int group_sum_comp(int row) { return ((row & 1) << 1) | (row >> 1); }
+
 // Sum the EPW per-group partial rows of a wave; afterwards every group holds the total.
 template <class C>
 __device__ __forceinline__ void frag_reduce_groups(Frag<C> &acc) {

@@ -48,7 +48,7 @@ __global__ __launch_bounds__(kBlockThreads) void gt_block_fwd_kernel(Csr g, cons
   float *outh = out + (size_t)head * F;
   float *attn_h = WRITE_ATTN ? attn_edge + (size_t)head * g.nnz : nullptr;
   const bool narrow = n <= 256;
-  const int kk = gl * EPW + gid;            // the edge of a chunk whose logit this lane keeps
+  const int kk = chunk_edge_of_lane<C>(gid, gl);  // the edge of a chunk whose logit this lane keeps
   const int stage = (lane % EPW) * G + lane / EPW;  // where lane's own edge goes in the de-interleaved scratch
 
   DFGNN_STAMP(0)
@@ -128,8 +128,7 @@ __global__ __launch_bounds__(kBlockThreads) void gt_block_fwd_kernel(Csr g, cons
       row = block_col(L, narrow, lb + k);
       if constexpr (WRITE_ATTN) attn_h[e0 + lb + k] = w * inv;
     });
-    frag_reduce_groups<C>(acc);
-    if (gid == 0) frag_store_full<C>(acc, inv, outh + (size_t)i * hf, gl);
+    block_store_row<C>(acc, inv, outh + (size_t)i * hf, gid, gl);
   }
   DFGNN_STAMP(5)
   if (threadIdx.x == 0) { DFGNN_STAMP(6) }

@@ -69,7 +69,7 @@ __global__ __launch_bounds__(kBlockThreads) void gt_block_bwd_kernel(
   const EdgeArr W{edge_global ? nullptr : L.lw, edge_global ? edge_ws + (size_t)head * g.nnz + e0 : nullptr};
   int *sci = reinterpret_cast<int *>(L.sc);
   const bool narrow = n <= 256;
-  const int kk = gl * EPW + gid;
+  const int kk = chunk_edge_of_lane<C>(gid, gl);
   const int stage = (lane % EPW) * G + lane / EPW;
   const size_t hoff = (size_t)head * F;
   const float *P_h = attn_edge + (size_t)head * g.nnz + e0;  // this range's slice of attn_edge
@@ -173,8 +173,7 @@ __global__ __launch_bounds__(kBlockThreads) void gt_block_bwd_kernel(
       w = W.load(lb + k);
       row = col_of(lb + k);
     });
-    frag_reduce_groups<C>(acc);
-    if (gid == 0) frag_store_full<C>(acc, 1.f, dQ + (size_t)(n0 + r) * hf + hoff, gl);
+    block_store_row<C>(acc, 1.f, dQ + (size_t)(n0 + r) * hf + hoff, gid, gl);
   }
   __syncthreads();
 
@@ -202,8 +201,7 @@ __global__ __launch_bounds__(kBlockThreads) void gt_block_bwd_kernel(
       csc_entry(cb + k, row, slot);
       w = P_h[slot];
     });
-    frag_reduce_groups<C>(acc);
-    if (gid == 0) frag_store_full<C>(acc, 1.f, dV + (size_t)(n0 + c) * hf + hoff, gl);
+    block_store_row<C>(acc, 1.f, dV + (size_t)(n0 + c) * hf + hoff, gid, gl);
   }
   __syncthreads();
 
@@ -220,8 +218,7 @@ __global__ __launch_bounds__(kBlockThreads) void gt_block_bwd_kernel(
       csc_entry(cb + k, row, slot);
       w = W.load(slot);
     });
-    frag_reduce_groups<C>(acc);
-    if (gid == 0) frag_store_full<C>(acc, 1.f, dK + (size_t)(n0 + c) * hf + hoff, gl);
+    block_store_row<C>(acc, 1.f, dK + (size_t)(n0 + c) * hf + hoff, gid, gl);
   }
 }
 
