@@ -42,6 +42,9 @@ def parse():
     ap.add_argument("--heads", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-graphs", type=int, default=128)
+    # rehearsal only: "gloo" lets several ranks share ONE GPU (collectives on host tensors) to exercise the N > 1
+    # code path on a single-GPU box; the driver's multi-GPU runs use the default (RCCL).
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"])
     return ap.parse_args()
 
 
@@ -69,11 +72,17 @@ def main():
     if world != args.gpus and rank == 0:
         print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
     assert torch.cuda.is_available(), "bench.py needs a GPU (the fused kernels have no CPU fallback)"
+    if args.dist_backend == "gloo":
+        local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    cdev = dev if args.dist_backend == "nccl" else torch.device("cpu")  # where collective buffers live
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
     import dfgnn_native
     import fused_gtconv
@@ -108,10 +117,10 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        e = torch.tensor([nnz], dtype=torch.int64, device=dev)
+        e = torch.tensor([nnz], dtype=torch.int64, device=cdev)
         dist.all_reduce(e)
         total_edges = int(e.item())
     else:
@@ -177,16 +186,19 @@ def main():
     # ---- forward-output all-gather (the inference-side exchange step), timed separately
     gather = None
     if world > 1:
-        mx = torch.tensor([m], dtype=torch.int64, device=dev)
+        mx = torch.tensor([m], dtype=torch.int64, device=cdev)
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         m_pad = int(mx.item())
-        send = torch.zeros(m_pad, h, f, device=dev)
-        recv = torch.empty(world * m_pad, h, f, device=dev)
+        send = torch.zeros(m_pad, h, f, device=cdev)
+        recv = torch.empty(world * m_pad, h, f, device=cdev)
 
         def infer_step():
             o = fused_gtconv.gt_hyper_inference(row_ptr, col_ind, rows, val, smem, Q.detach(), K.detach(), V.detach())[0]
             send[:m].copy_(o)
-            dist.all_gather_into_tensor(recv, send)
+            if args.dist_backend == "nccl":
+                dist.all_gather_into_tensor(recv, send)
+            else:
+                dist.all_gather(list(recv.chunk(world)), send)
 
         for _ in range(3):
             infer_step()
@@ -195,7 +207,7 @@ def main():
         for _ in range(args.steps):
             infer_step()
         barrier()
-        tg = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        tg = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=cdev)
         dist.all_reduce(tg, op=dist.ReduceOp.MAX)
         gather = {"ms_per_step": round(float(tg.item()) / args.steps * 1e3, 4),
                   "edges_per_s": total_edges * args.steps / float(tg.item()),
