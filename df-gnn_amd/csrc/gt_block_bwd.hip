@@ -14,6 +14,16 @@
 
 namespace dfgnn {
 
+// Diagnostic build only (-DDFGNN_STAMPS): phase boundaries in shader cycles (see gt_block.hip).
+#ifdef DFGNN_STAMPS
+__device__ unsigned long long *dfgnn_bwd_stamps = nullptr;
+#define DFGNN_BSTAMP(k)                                                                           \
+  if (threadIdx.x == 0 && dfgnn_bwd_stamps)                                                       \
+    dfgnn_bwd_stamps[((size_t)blockIdx.x * gridDim.y + blockIdx.y) * 16 + (k)] = __builtin_amdgcn_s_memtime();
+#else
+#define DFGNN_BSTAMP(k)
+#endif
+
 struct BwdLds {
   float *res;              // [n * F]   resident rows: V, K, dO, Q in turn
   float *lw;               // [ne]      dP, then dS * val  (CSR order)
@@ -76,6 +86,7 @@ __global__ __launch_bounds__(kBlockThreads) void gt_block_bwd_kernel(
   const float *valb = g.val ? g.val + e0 : nullptr;
 
   // ---- stage index arrays + V ------------------------------------------------------------------------------
+  DFGNN_BSTAMP(0)
   for (int i = threadIdx.x; i <= n; i += kBlockThreads) {
     L.rp[i] = g.row_ptr[n0 + i] - e0;
     L.cp[i] = col_ptr[n0 + i] - ce0;
@@ -114,6 +125,7 @@ __global__ __launch_bounds__(kBlockThreads) void gt_block_bwd_kernel(
   };
   load_resident(L.res, V + (size_t)n0 * hf + hoff, n, F, hf);
   __syncthreads();
+  DFGNN_BSTAMP(1)
 
   // ---- pass 1 (V resident): dP, row sums, dS -> lw --------------------------------------------------------
   {
@@ -159,11 +171,14 @@ __global__ __launch_bounds__(kBlockThreads) void gt_block_bwd_kernel(
       }
     }
   }
+  DFGNN_BSTAMP(2)
   __syncthreads();
+  DFGNN_BSTAMP(3)
 
   // ---- pass 2 (K resident): dQ ---------------------------------------------------------------------------------
   load_resident(L.res, K + (size_t)n0 * hf + hoff, n, F, hf);
   __syncthreads();
+  DFGNN_BSTAMP(4)
   for (int r = wave; r < n; r += kBlockWaves) {
     const int lb = __builtin_amdgcn_readfirstlane(L.rp[r]);
     const int deg = __builtin_amdgcn_readfirstlane(L.rp[r + 1]) - lb;
@@ -175,7 +190,9 @@ __global__ __launch_bounds__(kBlockThreads) void gt_block_bwd_kernel(
     });
     block_store_row<C>(acc, 1.f, dQ + (size_t)(n0 + r) * hf + hoff, gid, gl);
   }
+  DFGNN_BSTAMP(5)
   __syncthreads();
+  DFGNN_BSTAMP(6)
 
   // CSC entry t of this range -> (block-local row id, block-local CSR slot)
   auto csc_entry = [&](int t, int &row, int &slot) {
@@ -191,6 +208,7 @@ __global__ __launch_bounds__(kBlockThreads) void gt_block_bwd_kernel(
   // ---- pass 3 (dO resident): dV --------------------------------------------------------------------------------
   load_resident(L.res, dO + (size_t)n0 * hf + hoff, n, F, hf);
   __syncthreads();
+  DFGNN_BSTAMP(7)
   for (int c = wave; c < n; c += kBlockWaves) {
     const int cb = __builtin_amdgcn_readfirstlane(L.cp[c]);
     const int cdeg = __builtin_amdgcn_readfirstlane(L.cp[c + 1]) - cb;
@@ -203,11 +221,14 @@ __global__ __launch_bounds__(kBlockThreads) void gt_block_bwd_kernel(
     });
     block_store_row<C>(acc, 1.f, dV + (size_t)(n0 + c) * hf + hoff, gid, gl);
   }
+  DFGNN_BSTAMP(8)
   __syncthreads();
+  DFGNN_BSTAMP(9)
 
   // ---- pass 4 (Q resident): dK ---------------------------------------------------------------------------------
   load_resident(L.res, Q + (size_t)n0 * hf + hoff, n, F, hf);
   __syncthreads();
+  DFGNN_BSTAMP(10)
   for (int c = wave; c < n; c += kBlockWaves) {
     const int cb = __builtin_amdgcn_readfirstlane(L.cp[c]);
     const int cdeg = __builtin_amdgcn_readfirstlane(L.cp[c + 1]) - cb;
@@ -220,6 +241,7 @@ __global__ __launch_bounds__(kBlockThreads) void gt_block_bwd_kernel(
     });
     block_store_row<C>(acc, 1.f, dK + (size_t)(n0 + c) * hf + hoff, gid, gl);
   }
+  DFGNN_BSTAMP(11)
 }
 
 int launch_gt_block_bwd(const Csr &g, const Plan &p, const int *col_ptr, const int *row_ind, const int *val_idx,
@@ -238,3 +260,9 @@ int launch_gt_block_bwd(const Csr &g, const Plan &p, const int *col_ptr, const i
 }
 
 }  // namespace dfgnn
+
+#ifdef DFGNN_STAMPS
+extern "C" int dfgnn_debug_set_bwd_stamps(void *p) {
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(dfgnn::dfgnn_bwd_stamps), &p, sizeof(p));
+}
+#endif

@@ -43,3 +43,23 @@ print("corr(total, ne):", np.corrcoef(tot, ne)[0, 1], " ticks per edge:", (tot /
 print("nodes: mean", n.mean(), "max", n.max(), " edges mean", ne.mean(), "max", ne.max())
 order = np.argsort(t[:, 0]); starts = t[order, 0] - t[:, 0].min()
 print("start times of WGs #0,255,256,511,512,768,last:", [int(starts[i]) for i in (0, min(255,nfit-1), min(256,nfit-1), min(511,nfit-1), min(512,nfit-1), min(768,nfit-1), nfit-1)])
+
+# ---- backward kernel
+out, attn = gt.gt_hyper_forward(row_ptr, col_ind, rows, val, col_ptr, row_ind, val_idx, smem, Q, K, V)
+dO = torch.randn_like(out)
+for _ in range(2):
+    gt.gt_backward(row_ptr, col_ind, rows, val, col_ptr, row_ind, val_idx, smem, Q, K, V, attn, dO)
+sb = torch.zeros(nfit * 16, dtype=torch.int64, device=dev)
+L.dfgnn_debug_set_bwd_stamps.argtypes = [ctypes.c_void_p]
+assert L.dfgnn_debug_set_bwd_stamps(sb.data_ptr()) == 0
+torch.cuda.synchronize()
+e0.record(); gt.gt_backward(row_ptr, col_ind, rows, val, col_ptr, row_ind, val_idx, smem, Q, K, V, attn, dO); e1.record()
+torch.cuda.synchronize()
+tb = sb.cpu().numpy().reshape(nfit, 16)[:, :12].astype(np.float64)
+db = np.diff(tb, axis=1)
+bn = ["stage idx+V", "pass1 dP/dS", "barrier", "load K", "pass2 dQ", "barrier", "load dO", "pass3 dV", "barrier", "load Q", "pass4 dK"]
+print("BWD kernel ms", e0.elapsed_time(e1))
+for k, nm in enumerate(bn):
+    print(f"{nm:14s} mean {db[:,k].mean():9.0f}  p50 {np.median(db[:,k]):9.0f}  max {db[:,k].max():9.0f}")
+totb = tb[:, 11] - tb[:, 0]
+print("bwd total per WG mean", totb.mean(), "max", totb.max(), " sum/256:", totb.sum() / 256)
