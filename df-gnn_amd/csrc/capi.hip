@@ -146,11 +146,19 @@ int dfgnn_gt_softmax_gm_fwd(int m, int nnz, int h, int f, const int *row_ptr, co
 
 int dfgnn_gat_hyper_fwd(int m, int nnz, int h, int f, const int *row_ptr, const int *col_ind, const int *rows,
                         const float *attn_row, const float *attn_col, float negative_slope, const float *X,
-                        float *out, dfgnn_stream_t stream) {
+                        float *edge_ws, float *out, const int *plan, const int *plan_meta, dfgnn_stream_t stream) {
   if (int c = check_common(m, nnz, h, f, row_ptr, col_ind)) return c < 0 ? c : 0;
   if (!attn_row || !attn_col || !X || !out || (nnz > 0 && !rows)) return kErrBadArg;
   const Csr g{m, nnz, h, f, row_ptr, col_ind, rows, nullptr};
-  return launch_gat_hyper_fwd(g, attn_row, attn_col, negative_slope, X, out, as_stream(stream));
+  Plan p;
+  const bool v4 = (f % 4 == 0) && aligned16(X) && aligned16(out);
+  if (v4 && block_width_ok(f) && make_plan(p, plan, plan_meta, m, nnz, f)) {
+    if (int rc = launch_gat_block_fwd(g, p, attn_row, attn_col, negative_slope, X, edge_ws, out, as_stream(stream)))
+      return rc;
+    return launch_gat_hyper_fwd(g, attn_row, attn_col, negative_slope, X, out, p.spill(), p.num_spill,
+                                as_stream(stream));
+  }
+  return launch_gat_hyper_fwd(g, attn_row, attn_col, negative_slope, X, out, nullptr, 0, as_stream(stream));
 }
 
 static int gat_softmax_impl(bool use_lds, int m, int nnz, int h, int f, const int *row_ptr, const int *col_ind,

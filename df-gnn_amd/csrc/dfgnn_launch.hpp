@@ -99,7 +99,9 @@ int launch_gt_block_bwd(const Csr &g, const Plan &p, const int *col_ptr, const i
                         const float *Q, const float *K, const float *V, const float *attn_edge,
                         const float *grad_out, float *edge_ws, float *dQ, float *dK, float *dV, hipStream_t s);
 int launch_gat_hyper_fwd(const Csr &g, const float *attn_row, const float *attn_col, float slope,
-                         const float *X, float *out, hipStream_t s);
+                         const float *X, float *out, const int *chunks, int nchunks, hipStream_t s);
+int launch_gat_block_fwd(const Csr &g, const Plan &p, const float *attn_row, const float *attn_col, float slope,
+                         const float *X, float *edge_ws, float *out, hipStream_t s);
 int launch_gat_tiling_fwd(const Csr &g, const float *attn_row, const float *attn_col, float slope,
                           const float *X, float *out, hipStream_t s);
 int launch_gat_sddmm(const Csr &g, const float *attn_row, const float *attn_col, float slope, float *logits,

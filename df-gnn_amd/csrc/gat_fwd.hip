@@ -19,7 +19,8 @@ template <class C>
 __global__ __launch_bounds__(kBlock) void gat_hyper_fwd_kernel(Csr g, const float *__restrict__ attn_row,
                                                                const float *__restrict__ attn_col, float slope,
                                                                const float *__restrict__ X,
-                                                               float *__restrict__ out) {
+                                                               float *__restrict__ out,
+                                                               const int *__restrict__ chunks) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float *lw = lds;
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
@@ -28,8 +29,8 @@ __global__ __launch_bounds__(kBlock) void gat_hyper_fwd_kernel(Csr g, const floa
 
   const int head = blockIdx.y;
   const int h = g.h, f = g.f;
-  const int r0 = blockIdx.x * kHyperRows;
-  const int r1 = min(g.m, r0 + kHyperRows);
+  const int r0 = chunks ? chunks[2 * blockIdx.x] : blockIdx.x * kHyperRows;
+  const int r1 = chunks ? chunks[2 * blockIdx.x + 1] : min(g.m, r0 + kHyperRows);
   const size_t hf = (size_t)h * f;
   const float *Xh = X + (size_t)head * f;
   const float *arow_h = attn_row + head, *acol_h = attn_col + head;
@@ -90,13 +91,14 @@ __global__ __launch_bounds__(kBlock) void gat_sddmm_kernel(Csr g, const float *_
 }
 
 int launch_gat_hyper_fwd(const Csr &g, const float *attn_row, const float *attn_col, float slope,
-                         const float *X, float *out, hipStream_t s) {
-  const dim3 grid((g.m + kHyperRows - 1) / kHyperRows, g.h);
+                         const float *X, float *out, const int *chunks, int nchunks, hipStream_t s) {
+  const dim3 grid(chunks ? nchunks : (g.m + kHyperRows - 1) / kHyperRows, g.h);
+  if (grid.x == 0) return 0;
   const size_t lds = sizeof(float) * (kHyperCap + kWavesPerBlock * kScratchFloatsPerWave);
   const bool v4 = (g.f % 4 == 0) && aligned16(X) && aligned16(out);
   return dispatch_cfg(g.f, v4, [&](auto cfg) {
     using C = decltype(cfg);
-    gat_hyper_fwd_kernel<C><<<grid, kBlock, lds, s>>>(g, attn_row, attn_col, slope, X, out);
+    gat_hyper_fwd_kernel<C><<<grid, kBlock, lds, s>>>(g, attn_row, attn_col, slope, X, out, chunks);
     return launch_status();
   });
 }

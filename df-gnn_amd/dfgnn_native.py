@@ -23,7 +23,7 @@ SIGNATURES = {
     "dfgnn_gt_tiling_fwd": [_i, _i, _i, _i] + [_vp] * 8,
     "dfgnn_gt_softmax_fwd": [_i, _i, _i, _i] + [_vp] * 10,
     "dfgnn_gt_softmax_gm_fwd": [_i, _i, _i, _i] + [_vp] * 10,
-    "dfgnn_gat_hyper_fwd": [_i, _i, _i, _i] + [_vp] * 5 + [_f] + [_vp] * 3,
+    "dfgnn_gat_hyper_fwd": [_i, _i, _i, _i] + [_vp] * 5 + [_f] + [_vp] * 6,
     "dfgnn_gat_softmax_fwd": [_i, _i, _i, _i] + [_vp] * 5 + [_f] + [_vp] * 4,
     "dfgnn_gat_softmax_gm_fwd": [_i, _i, _i, _i] + [_vp] * 5 + [_f] + [_vp] * 4,
     "dfgnn_gat_tiling_fwd": [_i, _i, _i, _i] + [_vp] * 4 + [_f] + [_vp] * 3,

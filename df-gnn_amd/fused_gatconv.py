@@ -10,7 +10,10 @@ NotImplementedError rather than pretending.
 import torch
 
 import dfgnn_native as _n
-from _binding_util import check_contiguous, check_device, check_dtype, ptr, stream_ptr
+from _binding_util import check_contiguous, check_device, check_dtype, get_plan, ptr, stream_ptr
+
+# Set to False to force the general (plan-less) kernels; results are identical either way.
+USE_BLOCK_PLAN = True
 
 
 def _check(attn_row, attn_col, indptr, indices, rows, in_feat):
@@ -42,9 +45,11 @@ def gat_inference_hyper(smem_consume, attn_row, attn_col, indptr, indices, rows,
     m, nnz, h, f = _check(attn_row, attn_col, indptr, indices, rows, in_feat)
     with torch.cuda.device(in_feat.device):
         out = torch.empty_like(in_feat)
+        plan, meta, need_ws = get_plan(indptr, indices, f, USE_BLOCK_PLAN)
+        ws = torch.empty((h, nnz), dtype=torch.float32, device=in_feat.device) if need_ws else None
         _n.check(_n.lib().dfgnn_gat_hyper_fwd(m, nnz, h, f, ptr(indptr), ptr(indices), ptr(rows), ptr(attn_row),
-                                              ptr(attn_col), float(negative_slope), ptr(in_feat), ptr(out),
-                                              stream_ptr(in_feat.device)), "gat_inference_hyper")
+                                              ptr(attn_col), float(negative_slope), ptr(in_feat), ptr(ws), ptr(out),
+                                              plan, meta, stream_ptr(in_feat.device)), "gat_inference_hyper")
     return out
 
 

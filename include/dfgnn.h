@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define DFGNN_ABI_VERSION 3
+#define DFGNN_ABI_VERSION 4
 
 #define DFGNN_E_BADARG (-1)      /* negative size / NULL required pointer                      */
 #define DFGNN_E_UNSUPPORTED (-2) /* feature width outside the compiled range (f > 1024, or     */
@@ -121,10 +121,12 @@ int dfgnn_gt_softmax_gm_fwd(int m, int nnz, int h, int f, const int *row_ptr, co
 /* ---- GAT ---------------------------------------------------------------------------------------
  * attn_row, attn_col fp32[m, h]; X (in_feat) fp32[m, h, f].
  * replaces gat_inference_hyper (DFGNN/src/fused_gatconv/fused_gatconv.cpp:99-119,
- *                               fused_gatconv_hyper.cu:251-272) */
+ *                               fused_gatconv_hyper.cu:251-272)
+ * plan / plan_meta / edge_ws as in dfgnn_gt_hyper_fwd (edge_ws is needed whenever meta[8] > 0). */
 int dfgnn_gat_hyper_fwd(int m, int nnz, int h, int f, const int *row_ptr, const int *col_ind,
                         const int *rows, const float *attn_row, const float *attn_col,
-                        float negative_slope, const float *X, float *out, dfgnn_stream_t stream);
+                        float negative_slope, const float *X, float *edge_ws, float *out,
+                        const int *plan, const int *plan_meta, dfgnn_stream_t stream);
 
 /* replaces gat_inference_softmax (fused_gatconv.cpp:40-61, fused_gatconv_softmax.cu:33-56) and
  * gat_inference_softmax_gm (fused_gatconv.cpp:69-90, fused_gatconv_softmax_gm.cu) */

@@ -369,6 +369,19 @@ def test_block_kernels_match_oracle_and_general_path(oracle_mod, h, f, bs):
         gt.USE_BLOCK_PLAN = True
     for a, b in ((dQ, gQ), (dK, gK), (dV, gV)):
         assert torch.allclose(a, b, atol=1e-4, rtol=1e-3)
+    # GAT 'hyper' through the resident kernel (X resident) vs the oracle and the general kernel
+    import fused_gatconv as gat
+    ar, ac, X = S.gat_features(m, h, f, seed=6, device=DEV)
+    want_gat = oracle_mod.gat_forward(row_ptr.cpu().numpy(), col_ind.cpu().numpy(), ar.cpu().numpy(),
+                                      ac.cpu().numpy(), 0.2, X.cpu().numpy())
+    out_b = gat.gat_inference_hyper(smem, ar, ac, row_ptr, col_ind, rows, 0.2, X)
+    try:
+        gat.USE_BLOCK_PLAN = False
+        out_n = gat.gat_inference_hyper(smem, ar, ac, row_ptr, col_ind, rows, 0.2, X)
+    finally:
+        gat.USE_BLOCK_PLAN = True
+    _close(out_b, want_gat, "block GAT hyper")
+    assert torch.allclose(out_b, out_n, atol=1e-5, rtol=1e-4)
 
 
 def test_block_plan_mixed_fit_and_spill(oracle_mod):
@@ -407,3 +420,7 @@ def test_block_plan_mixed_fit_and_spill(oracle_mod):
     _close(dQ, wq, "mixed dQ")
     _close(dK, wk, "mixed dK")
     _close(dV, wv, "mixed dV")
+    import fused_gatconv as gat
+    ar, ac, X = S.gat_features(m, 1, 128, seed=6, device=DEV)
+    want_gat = oracle_mod.gat_forward(n(row_ptr), n(col_ind), n(ar), n(ac), 0.2, n(X))
+    _close(gat.gat_inference_hyper(smem, ar, ac, row_ptr, col_ind, rows, 0.2, X), want_gat, "mixed GAT hyper")

@@ -103,6 +103,20 @@ if "c4" in args:
          ms=sec * 1e3, edges_per_s=nnz / sec, max_abs_err_200_rows=max(errs), algorithmic_GBs=byt / sec / 1e9,
          hbm_frac=byt / sec / 1e9 / HBM, gather_GBs=nnz * 512 / sec / 1e9, graph_build_s=gen_s)
 
+if "c3gat" in args:
+    import fused_gatconv as _gatb
+    g = S.pattern_like(batch_size=1024, seed=1).to(dev)
+    A, rows, row_ptr, col_ind, val, col_ptr, row_ind, val_idx, smem = preprocess_Hyper_fw_bw(g)
+    m, nnz = g.num_nodes(), g.num_edges()
+    ar, ac, X = S.gat_features(m, 1, 128, seed=4, device=dev)
+    byt = 8 * m * 128 + 8 * m + 4 * (m + 1) + 8 * nnz
+    for use_plan in (True, False):
+        _gatb.USE_BLOCK_PLAN = use_plan
+        out, sec = benchmark(lambda: gat.GATConvFuse_inference_hyper(smem, ar, ac, row_ptr, col_ind, rows, 0.2, X))
+        emit(config=f"GAT 'hyper' on the C3 batch (PATTERN-like bs=1024 f=128) plan={use_plan}", edges=nnz, us=sec * 1e6,
+             edges_per_s=nnz / sec, algorithmic_GBs=byt / sec / 1e9, hbm_frac=byt / sec / 1e9 / HBM)
+    _gatb.USE_BLOCK_PLAN = True
+
 if "c5" in args:
     import fused_gtconv as _gtb
     for heads, use_plan in ((4, True), (4, False), (8, True), (8, False)):
