@@ -37,6 +37,38 @@ __global__ void plan_row_extent_kernel(int m, const int *__restrict__ row_ptr, c
   hi[i] = h;
 }
 
+// Exclusive scan of part[0 .. kPlanThreads) in place by wave 0 (lane l owns 16 consecutive entries, a wave-level
+// shuffle scan combines the lane totals).  FORWARD: part[k] <- op(identity, part[0..k)); else the mirror image
+// (part[k] <- op over part(k..end)).  Every thread of the workgroup must call it (it contains the barriers).
+template <bool FORWARD, class Op>
+__device__ __forceinline__ void plan_scan_partials(int *part, int identity, Op op) {
+  constexpr int PER = kPlanThreads / kWave;
+  __syncthreads();
+  if (threadIdx.x < kWave) {
+    const int lane = threadIdx.x;
+    int v[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) v[k] = part[FORWARD ? lane * PER + k : kPlanThreads - 1 - (lane * PER + k)];
+    int tot = identity;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) tot = op(tot, v[k]);
+    int incl = tot;  // inclusive scan of the lane totals
+#pragma unroll
+    for (int o = 1; o < kWave; o <<= 1) {
+      const int up = __shfl_up(incl, o, kWave);
+      if (lane >= o) incl = op(incl, up);
+    }
+    int run = __shfl_up(incl, 1, kWave);
+    if (lane == 0) run = identity;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      part[FORWARD ? lane * PER + k : kPlanThreads - 1 - (lane * PER + k)] = run;
+      run = op(run, v[k]);
+    }
+  }
+  __syncthreads();
+}
+
 // One workgroup.  (1) hi <- inclusive prefix max, lo <- inclusive suffix min.  (2) boundary after row i
 // iff pmax[i] <= i and smin[i+1] >= i+1.  (3) thread 0 merges consecutive closed ranges greedily while
 // they fit the LDS budget and emits fit blocks / spill chunks.
@@ -58,12 +90,7 @@ __global__ __launch_bounds__(kPlanThreads) void plan_cut_kernel(int m, int nnz, 
   int acc = -1;
   for (int i = b; i < e; ++i) acc = max(acc, hi[i]);
   part[t] = acc;
-  __syncthreads();
-  if (t == 0) {
-    int run = -1;
-    for (int k = 0; k < kPlanThreads; ++k) { const int v = part[k]; part[k] = run; run = max(run, v); }
-  }
-  __syncthreads();
+  plan_scan_partials<true>(part, -1, [](int a, int b) { return max(a, b); });
   acc = part[t];
   for (int i = b; i < e; ++i) { acc = max(acc, hi[i]); hi[i] = acc; }
   __syncthreads();
@@ -71,12 +98,7 @@ __global__ __launch_bounds__(kPlanThreads) void plan_cut_kernel(int m, int nnz, 
   acc = m;
   for (int i = e - 1; i >= b; --i) acc = min(acc, lo[i]);
   part[t] = acc;
-  __syncthreads();
-  if (t == 0) {
-    int run = m;
-    for (int k = kPlanThreads - 1; k >= 0; --k) { const int v = part[k]; part[k] = run; run = min(run, v); }
-  }
-  __syncthreads();
+  plan_scan_partials<false>(part, m, [](int a, int b) { return min(a, b); });
   acc = part[t];
   for (int i = e - 1; i >= b; --i) { acc = min(acc, lo[i]); lo[i] = acc; }
   __syncthreads();
@@ -84,12 +106,8 @@ __global__ __launch_bounds__(kPlanThreads) void plan_cut_kernel(int m, int nnz, 
   int cnt = 0;
   for (int i = b; i < e; ++i) cnt += (hi[i] <= i && (i + 1 == m || lo[i + 1] >= i + 1)) ? 1 : 0;
   part[t] = cnt;
-  __syncthreads();
-  if (t == 0) {
-    int run = 0;
-    for (int k = 0; k < kPlanThreads; ++k) { const int v = part[k]; part[k] = run; run += v; }
-    hdr[7] = run;  // number of natural ranges (temporary)
-  }
+  plan_scan_partials<true>(part, 0, [](int a, int b) { return a + b; });
+  if (t == kPlanThreads - 1) hdr[7] = part[t] + cnt;  // number of natural ranges (temporary)
   __syncthreads();
   int pos = part[t];
   for (int i = b; i < e; ++i)
