@@ -13,8 +13,13 @@ __device__ unsigned long long *dfgnn_stamps = nullptr;
 #define DFGNN_STAMP(k)                                                                            \
   if (threadIdx.x == 0 && dfgnn_stamps)                                                           \
     dfgnn_stamps[((size_t)blockIdx.x * gridDim.y + blockIdx.y) * 8 + (k)] = __builtin_amdgcn_s_memtime();
+__device__ unsigned long long *dfgnn_round_stamps = nullptr;   // [wg][8]: per-phase cycle sums of the MFMA rounds
+#define DFGNN_RT(var) unsigned long long var = __builtin_amdgcn_s_memtime();
+#define DFGNN_RACC(k, a, b) if (threadIdx.x == 0) racc[k] += (b) - (a);
 #else
 #define DFGNN_STAMP(k)
+#define DFGNN_RT(var)
+#define DFGNN_RACC(k, a, b)
 #endif
 
 // Per-edge fp32 values of a range (logits / exp values / dS): in LDS when the range's plan entry allows,
@@ -39,10 +44,11 @@ struct BlockLds {
 };
 
 // Layout must stay in step with plan.hip:bytes_of() (the plan guarantees it fits 160 KB).
-__device__ __forceinline__ BlockLds carve_block_lds(float *lds, int n, int ne, int f, int wave) {
+__device__ __forceinline__ BlockLds carve_block_lds(float *lds, int n, int ne, int f, int wave,
+                                                    int res_floats = -1) {
   BlockLds b;
   b.res = lds;
-  b.lw = b.res + (size_t)n * f;
+  b.lw = b.res + (res_floats >= 0 ? (size_t)res_floats : (size_t)n * f);
   b.rinv = b.lw + ((ne + 3) & ~3);
   b.rp = reinterpret_cast<int *>(b.rinv + ((n + 3) & ~3));
   b.sc = reinterpret_cast<int2 *>(b.rp + ((n + 1 + 3) & ~3)) + wave * kWave;
@@ -203,6 +209,25 @@ __device__ __forceinline__ void block_spmm(Frag<C> &acc, const float *res, int2 
       for (int u = 0; u < TRIP; ++u) frag_fma_pk<C>(acc, wv[u], v[u]);
     }
     wave_sync();
+  }
+}
+
+// ---- matrix-core logits (split-bf16) -----------------------------------------------------------------------------
+// The dense per-head feature contraction of a range, S = Q K^T, on MFMA: fp32 operands are split into two bf16
+// halves (x = hi + lo, |x - hi - lo| <= 2^-17 |x|) and  S ~= Qhi Khi^T + Qhi Klo^T + Qlo Khi^T  is accumulated in fp32
+// by v_mfma_f32_16x16x32_bf16 (relative error ~2^-16 per product, far inside the 1e-3 parity bar; the dropped
+// lo*lo term is ~2^-18).  One 16x16 tile costs 3 * F/32 MFMAs of 16 cycles instead of ~40 VALU wave-instructions
+// per 16 *edges*; the sparse structure is applied afterwards by gathering each row's edge logits from the tile panel.
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+__device__ __forceinline__ void split_bf16x8(const float4 &a, const float4 &b, bf16x8 &hi, bf16x8 &lo) {
+  const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const __bf16 h = (__bf16)x[j];
+    hi[j] = h;
+    lo[j] = (__bf16)(x[j] - (float)h);
   }
 }
 

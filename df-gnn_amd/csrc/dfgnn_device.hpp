@@ -45,6 +45,13 @@ constexpr int kDppXor1 = 0xB1, kDppXor2 = 0x4E, kDppHalfMirror = 0x141, kDppMirr
 
 // All-reduce over aligned groups of W lanes (W a power of two); every lane of the group gets the result.
 // All lanes of the group must be active.
+// Workgroup barrier that only drains LDS traffic (s_waitcnt lgkmcnt(0); s_barrier): __syncthreads() also
+// waits vmcnt(0), which would expose the latency of global loads deliberately left in flight across the
+// barrier (register prefetch of the next round's operands).
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 template <int W>
 __device__ __forceinline__ float lanes_sum(float v) {
   if constexpr (W >= 2) v += dpp_perm<kDppXor1>(v);

@@ -23,6 +23,10 @@ nfit = row_ptr._dfgnn_plans[128].num_fit
 st = torch.zeros(nfit * 8, dtype=torch.int64, device=dev)
 L.dfgnn_debug_set_stamps.argtypes = [ctypes.c_void_p]
 assert L.dfgnn_debug_set_stamps(st.data_ptr()) == 0
+rs = torch.zeros(nfit * 8, dtype=torch.int64, device=dev)
+if hasattr(L, "dfgnn_debug_set_round_stamps"):
+    L.dfgnn_debug_set_round_stamps.argtypes = [ctypes.c_void_p]
+    L.dfgnn_debug_set_round_stamps(rs.data_ptr())
 torch.cuda.synchronize()
 e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
 e0.record(); gt.gt_hyper_forward(row_ptr, col_ind, rows, val, col_ptr, row_ind, val_idx, smem, Q, K, V); e1.record()
@@ -39,6 +43,10 @@ tot = t[:, 5] - t[:, 0]
 print("total per WG mean", tot.mean(), "max", tot.max(), "min", tot.min())
 print("span of kernel (ticks):", t[:, 5].max() - t[:, 0].min())
 print("sum of WG totals / 256 CUs:", tot.sum() / 256)
+rr = rs.cpu().numpy().reshape(nfit, 8).astype(np.float64)
+if rr[:, 5].sum() > 0:
+    print("MFMA rounds per WG mean", rr[:, 5].mean(), " per-WG cycle sums: split+prefetch %.0f  tiles %.0f  barrier1 %.0f  gather %.0f  barrier2 %.0f"
+          % tuple(rr[:, k].mean() for k in range(5)))
 print("corr(total, ne):", np.corrcoef(tot, ne)[0, 1], " ticks per edge:", (tot / np.maximum(ne, 1)).mean())
 print("nodes: mean", n.mean(), "max", n.max(), " edges mean", ne.mean(), "max", ne.max())
 order = np.argsort(t[:, 0]); starts = t[order, 0] - t[:, 0].min()
