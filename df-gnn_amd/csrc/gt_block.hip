@@ -48,14 +48,21 @@ __global__ __launch_bounds__(kBlockThreads) void gt_block_fwd_kernel(Csr g, cons
   const int PS = npad + 4;                        // floats per panel row
   const int res_mfma = max(n * F, npad * KS);     // floats: Khi + Klo take npad*KS*2 bf16 each
   const int cols_b = ((ne * (n <= 256 ? 1 : 2)) + 19) & ~15;
-  const size_t mfma_bytes = ((size_t)res_mfma + ((ne + 3) & ~3) + ((n + 3) & ~3) + ((n + 4) & ~3)) * 4 +
-                            kBlockScratchBytes + cols_b + (size_t)32 * PS * 4 + (size_t)32 * KS * 4;
-  const bool use_mfma = kMfmaCfg && !edge_global && n <= 256 && mfma_bytes <= (size_t)lds_bytes;
-  const BlockLds L = carve_block_lds(lds, n, edge_global ? 0 : ne, F, wave, use_mfma ? res_mfma : -1);
+  const size_t mfma_base = ((size_t)res_mfma + ((n + 3) & ~3) + ((n + 4) & ~3)) * 4 + kBlockScratchBytes + cols_b +
+                           (size_t)32 * PS * 4 + (size_t)32 * KS * 4;
+  const bool mfma_cfg_ok = kMfmaCfg && n <= 256;
+  // the per-edge array stays in LDS if the matrix-core layout still fits with it, else it goes to the global
+  // scratch (attn_edge in training, the caller's edge_ws in inference) -- that keeps ranges up to ~165 nodes
+  // (f = 128) on the matrix cores
+  const bool mfma_lw_lds = mfma_cfg_ok && !edge_global && mfma_base + (size_t)((ne + 3) & ~3) * 4 <= (size_t)lds_bytes;
+  const bool mfma_lw_glob = mfma_cfg_ok && !mfma_lw_lds && edge_ws != nullptr && mfma_base <= (size_t)lds_bytes;
+  const bool use_mfma = mfma_lw_lds || mfma_lw_glob;
+  const bool w_global = use_mfma ? mfma_lw_glob : edge_global;
+  const BlockLds L = carve_block_lds(lds, n, w_global ? 0 : ne, F, wave, use_mfma ? res_mfma : -1);
   float *panel = reinterpret_cast<float *>(L.cols + cols_b);
   __bf16 *qhi = reinterpret_cast<__bf16 *>(panel + (size_t)32 * PS), *qlo = qhi + (size_t)32 * KS;  // Q rows of a round
   // exp values between the passes: LDS, or (large ranges) this range's slice of the global scratch
-  const EdgeArr W{edge_global ? nullptr : L.lw, edge_global ? edge_ws + (size_t)head * g.nnz + e0 : nullptr};
+  const EdgeArr W{w_global ? nullptr : L.lw, w_global ? edge_ws + (size_t)head * g.nnz + e0 : nullptr};
   int *sci = reinterpret_cast<int *>(L.sc);  // pass A stages columns only (first 256 B of the scratch)
   const float *Qh = Q + (size_t)head * F;
   float *outh = out + (size_t)head * F;
@@ -85,7 +92,7 @@ __global__ __launch_bounds__(kBlockThreads) void gt_block_fwd_kernel(Csr g, cons
         *reinterpret_cast<bf16x8 *>(klo + (size_t)row * KS + 8 * c8) = lo;
       }
       // edge values go to LDS once (coalesced), so the per-round gather phase issues no global loads at all
-      if (g.val)
+      if (g.val && !w_global)
         for (int e = threadIdx.x; e < ne; e += kBlockThreads) L.lw[e] = g.val[e0 + e];
     }
   }
@@ -174,7 +181,7 @@ __global__ __launch_bounds__(kBlockThreads) void gt_block_fwd_kernel(Csr g, cons
             float sv = -INFINITY;
             if (lane < deg) {
               sv = prow[block_col(L, narrow, lb + lane)];
-              if (g.val) sv *= L.lw[lb + lane];
+              if (g.val) sv *= w_global ? g.val[e0 + lb + lane] : L.lw[lb + lane];
             }
             const float mx = wave_max(sv);
             const float pv = (sv == -INFINITY) ? 0.f : fast_exp(sv - mx);
@@ -185,7 +192,7 @@ __global__ __launch_bounds__(kBlockThreads) void gt_block_fwd_kernel(Csr g, cons
             float mx = -INFINITY;
             for (int e = lane; e < deg; e += kWave) {
               float sv = prow[block_col(L, narrow, lb + e)];
-              if (g.val) sv *= L.lw[lb + e];
+              if (g.val) sv *= w_global ? g.val[e0 + lb + e] : L.lw[lb + e];
               W.store(lb + e, sv);
               mx = fmaxf(mx, sv);
             }
@@ -251,7 +258,7 @@ __global__ __launch_bounds__(kBlockThreads) void gt_block_fwd_kernel(Csr g, cons
         }
         wave_sync();
         // lane l wrote slot c0 + kk(l) and now reads slot l + 64 j: order the wave's global traffic first
-        if (edge_global) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        if (w_global) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         float mx = -INFINITY;
         for (int e = lane; e < deg; e += kWave) mx = fmaxf(mx, W.load(lb + e));
         mx = wave_max(mx);

@@ -57,7 +57,9 @@ def gt_hyper_inference(indptr, indices, rows, val, smem_consume, Q, K, V):
     with torch.cuda.device(Q.device):
         out = torch.empty_like(Q)
         plan, meta, need_ws = get_plan(indptr, indices, f, USE_BLOCK_PLAN)
-        ws = torch.empty((h, nnz), dtype=torch.float32, device=Q.device) if need_ws else None
+        # scratch for per-edge values: required when the plan has edge-global ranges, and it lets mid-size ranges
+        # use the matrix-core logits path (their per-edge array moves out of LDS to make room for the tile panel)
+        ws = torch.empty((h, nnz), dtype=torch.float32, device=Q.device) if plan is not None else None
         _n.check(_n.lib().dfgnn_gt_hyper_fwd(m, nnz, h, f, ptr(indptr), ptr(indices), ptr(rows), ptr(val),
                                              ptr(Q), ptr(K), ptr(V), None, ptr(ws), ptr(out), plan, meta,
                                              stream_ptr(Q.device)), "gt_hyper_inference")
