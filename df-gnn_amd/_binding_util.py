@@ -97,6 +97,8 @@ def get_plan(indptr, indices, f, enable=True):
     Returns (plan_ptr, meta_ptr, needs_edge_scratch) for the C ABI, or (None, None, False)."""
     if not enable or f % 4 != 0 or indices.size(0) == 0:
         return None, None, False
+    if indices.size(0) < 8 * (indptr.size(0) - 1):
+        return None, None, False  # low-degree graphs take the row-per-lane-group kernels (capi.hip:low_degree)
     key = (indices.data_ptr(), indices.size(0), indptr._version, indices._version, f)
     cache = indptr.__dict__.setdefault("_dfgnn_plans", {})
     plan = cache.get(f)

@@ -60,6 +60,7 @@ int dfgnn_gt_hyper_fwd(int m, int nnz, int h, int f, const int *row_ptr, const i
     if (int rc = launch_gt_block_fwd(g, p, Q, K, V, attn_edge, edge_ws, out, as_stream(stream))) return rc;
     return launch_gt_hyper_fwd(g, Q, K, V, attn_edge, out, p.spill(), p.num_spill, as_stream(stream));
   }
+  if (low_degree(m, nnz)) return launch_gt_lowdeg_fwd(g, Q, K, V, attn_edge, out, as_stream(stream));
   return launch_gt_hyper_fwd(g, Q, K, V, attn_edge, out, nullptr, 0, as_stream(stream));
 }
 
@@ -108,6 +109,9 @@ int dfgnn_gt_bwd(int m, int nnz, int h, int f, const int *row_ptr, const int *co
     chunks = p.spill();
     nchunks = p.num_spill;
   }
+  if (!chunks && low_degree(m, nnz))
+    return launch_gt_lowdeg_bwd(g, col_ptr, row_ind, val_idx, Q, K, V, attn_edge, grad_out, grad_edge, dQ, dK, dV,
+                                as_stream(stream));
   if (int rc = launch_gt_bwd_rows(g, K, V, attn_edge, grad_out, grad_edge, dQ, chunks, nchunks, as_stream(stream)))
     return rc;
   return launch_gt_bwd_cols(g, col_ptr, row_ind, val_idx, Q, attn_edge, grad_edge, grad_out, dK, dV, chunks,

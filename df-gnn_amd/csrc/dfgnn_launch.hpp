@@ -98,6 +98,13 @@ int launch_gt_bwd_cols(const Csr &g, const int *col_ptr, const int *row_ind, con
 int launch_gt_block_bwd(const Csr &g, const Plan &p, const int *col_ptr, const int *row_ind, const int *val_idx,
                         const float *Q, const float *K, const float *V, const float *attn_edge,
                         const float *grad_out, float *edge_ws, float *dQ, float *dK, float *dV, hipStream_t s);
+int launch_gt_lowdeg_fwd(const Csr &g, const float *Q, const float *K, const float *V, float *attn_edge, float *out,
+                         hipStream_t s);
+int launch_gt_lowdeg_bwd(const Csr &g, const int *col_ptr, const int *row_ind, const int *val_idx, const float *Q,
+                         const float *K, const float *V, const float *attn_edge, const float *grad_out,
+                         float *grad_edge, float *dQ, float *dK, float *dV, hipStream_t s);
+// graphs with fewer than kBlockMinAvgDegree edges per row on average take the row-per-lane-group kernels
+inline bool low_degree(int m, int nnz) { return (long)nnz < (long)kBlockMinAvgDegree * m; }
 int launch_gat_hyper_fwd(const Csr &g, const float *attn_row, const float *attn_col, float slope,
                          const float *X, float *out, const int *chunks, int nchunks, hipStream_t s);
 int launch_gat_block_fwd(const Csr &g, const Plan &p, const float *attn_row, const float *attn_col, float slope,
