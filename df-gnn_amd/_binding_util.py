@@ -49,6 +49,22 @@ def ptr(t):
     return t.data_ptr() if t is not None else None
 
 
+def val_ptr(val):
+    """Edge values for the C ABI: NULL when they are all ones (include/dfgnn.h: "NULL means all ones"), which is
+    what every reference flow passes (A.val of an unweighted adjacency, DFGNN/layers/util.py:82-142) and lets the
+    kernels skip the per-edge multiply.  The test runs once per tensor version (one device reduction + sync)."""
+    if val is None:
+        return None
+    cached = getattr(val, "_dfgnn_unit", None)
+    if cached is None or cached[0] != val._version:
+        cached = (val._version, bool((val == 1).all().item()) if val.numel() else True)
+        try:
+            val._dfgnn_unit = cached
+        except AttributeError:
+            pass
+    return None if cached[1] else val.data_ptr()
+
+
 # ---- block plan cache -----------------------------------------------------------------------------
 class BlockPlan:
     """Device plan buffer + its 12 host header words (include/dfgnn.h, dfgnn_plan_build)."""

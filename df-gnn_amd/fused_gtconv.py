@@ -14,7 +14,7 @@ import torch
 
 import dfgnn_native as _n
 from _binding_util import (as_int32, check_contiguous, check_device, check_dtype, check_feat3, get_plan, ptr,
-                           stream_ptr)
+                           stream_ptr, val_ptr)
 
 # Set to False to force the general (plan-less) kernels; results are identical either way.
 USE_BLOCK_PLAN = True
@@ -60,7 +60,7 @@ def gt_hyper_inference(indptr, indices, rows, val, smem_consume, Q, K, V):
         # scratch for per-edge values: required when the plan has edge-global ranges, and it lets mid-size ranges
         # use the matrix-core logits path (their per-edge array moves out of LDS to make room for the tile panel)
         ws = torch.empty((h, nnz), dtype=torch.float32, device=Q.device) if plan is not None else None
-        _n.check(_n.lib().dfgnn_gt_hyper_fwd(m, nnz, h, f, ptr(indptr), ptr(indices), ptr(rows), ptr(val),
+        _n.check(_n.lib().dfgnn_gt_hyper_fwd(m, nnz, h, f, ptr(indptr), ptr(indices), ptr(rows), val_ptr(val),
                                              ptr(Q), ptr(K), ptr(V), None, ptr(ws), ptr(out), plan, meta,
                                              stream_ptr(Q.device)), "gt_hyper_inference")
     return [out]
@@ -86,7 +86,7 @@ def gt_hyper_forward(row_ptr, col_ind, rows, val, col_ptr, row_ind, val_idx, sme
         out = torch.empty_like(Q)
         attn_edge = torch.empty((h, nnz), dtype=torch.float32, device=Q.device)
         plan, meta, _ = get_plan(row_ptr, col_ind, f, USE_BLOCK_PLAN)
-        _n.check(_n.lib().dfgnn_gt_hyper_fwd(m, nnz, h, f, ptr(row_ptr), ptr(col_ind), ptr(rows), ptr(val),
+        _n.check(_n.lib().dfgnn_gt_hyper_fwd(m, nnz, h, f, ptr(row_ptr), ptr(col_ind), ptr(rows), val_ptr(val),
                                              ptr(Q), ptr(K), ptr(V), ptr(attn_edge), None, ptr(out), plan, meta,
                                              stream_ptr(Q.device)), "gt_hyper_forward")
     return [out, attn_edge]
@@ -115,7 +115,7 @@ def gt_backward(row_ptr, col_ind, rows, val, col_ptr, row_ind, val_idx, smem_con
         grad_edge = torch.empty((h, nnz), dtype=torch.float32, device=Q.device)
         dQ, dK, dV = torch.empty_like(Q), torch.empty_like(K), torch.empty_like(V)
         plan, meta, _ = get_plan(row_ptr, col_ind, f, USE_BLOCK_PLAN)
-        _n.check(_n.lib().dfgnn_gt_bwd(m, nnz, h, f, ptr(row_ptr), ptr(col_ind), ptr(rows), ptr(val),
+        _n.check(_n.lib().dfgnn_gt_bwd(m, nnz, h, f, ptr(row_ptr), ptr(col_ind), ptr(rows), val_ptr(val),
                                        ptr(col_ptr), ptr(row_ind), ptr(val_idx), ptr(Q), ptr(K), ptr(V),
                                        ptr(attn_edge), ptr(grad), ptr(grad_edge), ptr(dQ), ptr(dK), ptr(dV),
                                        plan, meta, stream_ptr(Q.device)), "gt_backward")

@@ -327,16 +327,20 @@ def test_block_plan_structure():
     assert p2.meta[0] == 0 and p2.meta[1] == (c.num_nodes() + 15) // 16
 
 
+@pytest.mark.parametrize("unit_val", [False, True])
 @pytest.mark.parametrize("h,f,bs", [(1, 128, 24), (4, 32, 24), (2, 64, 10), (1, 16, 60), (1, 256, 6), (1, 512, 3)])
-def test_block_kernels_match_oracle_and_general_path(oracle_mod, h, f, bs):
-    """'hyper' with the block plan (K/V resident in LDS) vs the oracle and vs the plan-less kernels."""
+def test_block_kernels_match_oracle_and_general_path(oracle_mod, h, f, bs, unit_val):
+    """'hyper' with the block plan (K/V resident in LDS) vs the oracle and vs the plan-less kernels.
+    unit_val: all-ones edge values reach the C ABI as NULL and take the one-pass forward (K and V resident
+    together); weighted edges take the two-pass forward."""
     import fused_gtconv as gt
     from DFGNN.layers import preprocess_Hyper_fw_bw
     from DFGNN.utils import synthetic as S
     kw = dict(mean_nodes=40, std_nodes=5, lo=30, hi=50, mean_deg=15) if f >= 512 else {}  # must fit 160 KB of LDS
     g = S.pattern_like(batch_size=bs, seed=21 + f, **kw).to(DEV)
     A, rows, row_ptr, col_ind, val, col_ptr, row_ind, val_idx, smem = preprocess_Hyper_fw_bw(g)
-    val = (torch.rand_like(val) + 0.5)
+    if not unit_val:
+        val = (torch.rand_like(val) + 0.5)
     m = g.num_nodes()
     Q, K, V = S.gt_features(m, h, f, seed=3, device=DEV)
     want, want_attn = oracle_mod.gt_forward(row_ptr.cpu().numpy(), col_ind.cpu().numpy(), val.cpu().numpy(),
