@@ -137,12 +137,13 @@ def main():
         attn = torch.empty(h, nnz, device=dev)
         gedge = torch.empty(h, nnz, device=dev)
         dQ, dK, dV = torch.empty_like(Q), torch.empty_like(Q), torch.empty_like(Q)
-    from _binding_util import get_plan
+    from _binding_util import get_plan, val_ptr
     plan, plan_meta, _ = get_plan(row_ptr, col_ind, f, fused_gtconv.USE_BLOCK_PLAN)
+    VP = val_ptr(val)  # NULL for unit edge values, exactly as the binding passes it (fused_gtconv.py)
     calls = {
-        "gt_hyper_fwd": lambda: L.dfgnn_gt_hyper_fwd(m, nnz, h, f, P(row_ptr), P(col_ind), P(rows), P(val), P(Q), P(K),
+        "gt_hyper_fwd": lambda: L.dfgnn_gt_hyper_fwd(m, nnz, h, f, P(row_ptr), P(col_ind), P(rows), VP, P(Q), P(K),
                                                      P(V), P(attn), None, P(out), plan, plan_meta, stream),
-        "gt_bwd": lambda: L.dfgnn_gt_bwd(m, nnz, h, f, P(row_ptr), P(col_ind), P(rows), P(val), P(col_ptr), P(row_ind),
+        "gt_bwd": lambda: L.dfgnn_gt_bwd(m, nnz, h, f, P(row_ptr), P(col_ind), P(rows), VP, P(col_ptr), P(row_ind),
                                          P(val_idx), P(Q), P(K), P(V), P(attn), P(dO), P(gedge), P(dQ), P(dK), P(dV),
                                          plan, plan_meta, stream),
         "gt_bwd_rows(general)": lambda: L.dfgnn_gt_bwd_rows(m, nnz, h, f, P(row_ptr), P(col_ind), P(rows), P(val), P(K), P(V),
@@ -166,13 +167,13 @@ def main():
     dom = max(("gt_hyper_fwd", "gt_bwd"), key=kernel_us.get)  # the launches the timed step actually runs
     achieved = abytes[dom] / (kernel_us[dom] * 1e-6) / 1e9
     # HBM bytes per launch from PMC counters (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc passes on this
-    # exact workload; profiles/r01_pmc_block_kernels.json).  bench.py cannot collect counters itself, so the figure
+    # exact workload; profiles/r01_pmc_dense_kernels.json).  bench.py cannot collect counters itself, so the figure
     # is reported only when the workload matches the profiled one, else null.
     traffic = None
     try:
-        prof = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_block_kernels.json")))
+        prof = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_dense_kernels.json")))
         if f"m={m}, nnz={nnz}" in prof["workload"] and h == 1 and f == 128:
-            key = {"gt_hyper_fwd": "gt_block_fwd_kernel", "gt_bwd": "gt_block_bwd_kernel"}[dom]
+            key = {"gt_hyper_fwd": "gt_dense_fwd_kernel", "gt_bwd": "gt_dense_bwd_kernel"}[dom]
             traffic = int(prof["traffic"][key]["total_bytes"])
     except Exception:
         traffic = None

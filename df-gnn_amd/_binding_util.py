@@ -86,6 +86,11 @@ class BlockPlan:
     def num_edge_global(self):
         return self.meta[8]
 
+    @property
+    def num_dense(self):
+        """Fit ranges marked for the matrix-core kernels (they come first in the list)."""
+        return self.meta[9]
+
     def ptrs(self):
         import ctypes
         return self.buf.data_ptr(), ctypes.addressof(self._meta_c)

@@ -11,7 +11,7 @@ inline hipStream_t as_stream(dfgnn_stream_t s) { return reinterpret_cast<hipStre
 // A plan is used only if it was built for exactly this (m, nnz, f) and LDS budget; otherwise the call
 // silently takes the general kernels (same results, no LDS residency).
 inline bool make_plan(Plan &p, const int *plan_dev, const int *meta, int m, int nnz, int f) {
-  p = Plan{nullptr, 0, 0, 0, 0, m, nnz, f, 0};
+  p = Plan{nullptr, 0, 0, 0, 0, m, nnz, f, 0, 0};
   if (!plan_dev || !meta) return false;
   if (meta[4] != m || meta[5] != nnz || meta[6] != f || meta[7] != kBlockLdsBudget) return false;
   if (meta[0] <= 0) return false;
@@ -19,7 +19,7 @@ inline bool make_plan(Plan &p, const int *plan_dev, const int *meta, int m, int 
   // by the per-edge gathers: a 1024-thread workgroup per range only adds fixed cost there (measured on the
   // Peptides-like config: 279 us resident vs 180 us general for fwd+bwd), so such graphs keep the general kernels.
   if ((long)nnz < (long)kBlockMinAvgDegree * m) return false;
-  p = Plan{plan_dev, meta[0], meta[1], meta[2], meta[3], m, nnz, f, meta[8]};
+  p = Plan{plan_dev, meta[0], meta[1], meta[2], meta[3], m, nnz, f, meta[8], meta[9]};
   return true;
 }
 

@@ -38,10 +38,13 @@ constexpr int kBlockMergeNodes = 256;                    // small graphs are mer
 
 constexpr int kPlanHeader = 12;                          // int32 header words of a plan buffer
 constexpr int kPlanEdgeGlobal = 1 << 30;                 // flag on a fit range's n1: per-edge array in global scratch
+constexpr int kPlanDense = 1 << 29;                      // flag on a fit range's n1: qualifies for the matrix-core kernels
+constexpr int kPlanRangeMask = ~(kPlanEdgeGlobal | kPlanDense);
 
 struct Plan {              // host view of a built plan (see plan.hip for the device layout)
   const int *dev;          // device buffer, may be null (= no plan: general kernels only)
   int num_fit, num_spill, max_fit_nodes, max_fit_edges, m, nnz, f, num_edge_global;
+  int num_dense;           // the first num_dense fit ranges carry kPlanDense (gt_dense.hip)
   const int *fit() const { return dev + kPlanHeader; }
   const int *spill() const { return dev + kPlanHeader + 2 * (size_t)m; }
 };
@@ -84,6 +87,12 @@ int launch_gt_hyper_fwd(const Csr &g, const float *Q, const float *K, const floa
 bool block_width_ok(int f);
 int launch_gt_block_fwd(const Csr &g, const Plan &p, const float *Q, const float *K, const float *V,
                         float *attn_edge, float *edge_ws, float *out, hipStream_t s);
+// matrix-core kernels over the first p.num_dense fit ranges (unit edge values only)
+int launch_gt_dense_fwd(const Csr &g, const Plan &p, const float *Q, const float *K, const float *V,
+                        float *attn_edge, float *out, hipStream_t s);
+int launch_gt_dense_bwd(const Csr &g, const Plan &p, const float *Q, const float *K, const float *V,
+                        const float *attn_edge, const float *grad_out, float *dQ, float *dK, float *dV,
+                        hipStream_t s);
 int launch_gt_tiling_fwd(const Csr &g, const float *Q, const float *K, const float *V, float *out,
                          hipStream_t s);
 int launch_gt_sddmm(const Csr &g, const float *Q, const float *K, float *logits, hipStream_t s);

@@ -19,7 +19,7 @@ __global__ __launch_bounds__(kBlockThreads) void gat_block_fwd_kernel(Csr g, con
   constexpr int G = C::G, F = C::G * C::VEC * C::NCH;
   const int n0 = fit[2 * blockIdx.x], n1raw = fit[2 * blockIdx.x + 1];
   const bool edge_global = (n1raw & kPlanEdgeGlobal) != 0;
-  const int n1 = n1raw & ~kPlanEdgeGlobal;
+  const int n1 = n1raw & kPlanRangeMask;
   const int n = n1 - n0;
   const int head = blockIdx.y, h = g.h;
   const size_t hf = (size_t)h * F;

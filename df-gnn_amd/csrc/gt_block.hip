@@ -17,7 +17,6 @@
 // mis-structures the `for(;;){ticket; if (r>=n) break; ...}` loop around an aggregated LDS atomic: the
 // kernel never terminated on hardware).
 #include "dfgnn_block.hpp"
-#include "dfgnn_dense.hpp"
 
 namespace dfgnn {
 
@@ -28,32 +27,17 @@ __global__ __launch_bounds__(kBlockThreads) void gt_block_fwd_kernel(Csr g, cons
                                                                      const float *__restrict__ V,
                                                                      float *__restrict__ attn_edge,
                                                                      float *__restrict__ edge_ws,
-                                                                     float *__restrict__ out, int lds_bytes, int dense) {
+                                                                     float *__restrict__ out, int lds_bytes) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int G = C::G, EPW = C::EPW, F = C::G * C::VEC * C::NCH;  // F == g.f (checked by the launcher)
   const int n0 = fit[2 * blockIdx.x], n1raw = fit[2 * blockIdx.x + 1];
   const bool edge_global = (n1raw & kPlanEdgeGlobal) != 0;
-  const int n1 = n1raw & ~kPlanEdgeGlobal;
+  const int n1 = n1raw & kPlanRangeMask;
   const int n = n1 - n0;
   const int head = blockIdx.y;
   const size_t hf = (size_t)g.h * F;
   const int e0 = g.row_ptr[n0];
   const int ne = g.row_ptr[n1] - e0;
-  bool done = false;  // block-uniform
-  if constexpr (DenseCfg<F>::ok) {
-    // matrix-core form (dfgnn_dense.hpp): dense enough, unweighted, at most 255 nodes
-    if (dense && !g.val && g.rows && n <= kDenseMaxNodes && dense_worthwhile(n, ne) &&
-        dense_lds_bytes(n, F) <= (size_t)lds_bytes)
-      done = (n <= kDenseChunkRows)
-                 ? gt_block_fwd_dense<F, WRITE_ATTN, 1>(lds, lds_bytes, g, n0, n, e0, ne, head, Q, K, V, attn_edge, out)
-                 : gt_block_fwd_dense<F, WRITE_ATTN, 2>(lds, lds_bytes, g, n0, n, e0, ne, head, Q, K, V, attn_edge, out);
-  }
-  if (done) {
-#ifdef DFGNN_STAMPS
-    if (threadIdx.x == 0 && dfgnn_stamps) dfgnn_stamps[((size_t)blockIdx.x * gridDim.y + blockIdx.y) * 8 + 7] = ((unsigned long long)n << 32) | (unsigned)ne;
-#endif
-    return;
-  }
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
   const int gid = lane / G, gl = lane % G;
   // Matrix-core logits (dfgnn_block.hpp): K lives in LDS as two bf16 halves, rows padded to a multiple of 16 and
@@ -336,28 +320,38 @@ bool block_width_ok(int f) {
   }) == 1;
 }
 
+// DFGNN_DENSE=0 (diagnostic switch) keeps every range on the edge-walking kernels.
+bool dense_enabled() {
+  static const bool on = [] { const char *e = getenv("DFGNN_DENSE"); return !e || atoi(e) != 0; }();
+  return on;
+}
+
 int launch_gt_block_fwd(const Csr &g, const Plan &p, const float *Q, const float *K, const float *V,
                         float *attn_edge, float *edge_ws, float *out, hipStream_t s) {
   if (p.num_fit == 0) return 0;
+  // Dense ranges with unit edge values go to the matrix-core kernel (gt_dense.hip); they come first in the list.
+  const int first = (!g.val && g.rows && dense_enabled()) ? p.num_dense : 0;
+  if (first > 0)
+    if (int rc = launch_gt_dense_fwd(g, p, Q, K, V, attn_edge, out, s)) return rc;
+  if (first == p.num_fit) return 0;
   // Ranges whose exp values do not fit LDS park them in global memory: the training forward lends its own
   // attn_edge output for that (it is overwritten with the normalised values in pass B), inference needs
   // the caller's scratch.
   if (!edge_ws) edge_ws = attn_edge;
   if (p.num_edge_global > 0 && !edge_ws) return kErrBadArg;
-  const dim3 grid(p.num_fit, g.h);
+  const dim3 grid(p.num_fit - first, g.h);
+  const int *fit = p.fit() + 2 * (size_t)first;
   const size_t lds = kLdsBytes;  // one workgroup per CU either way; the matrix-core layout needs the headroom
-  // diagnostic switch: DFGNN_DENSE=0 keeps every range on the edge-walking form
-  static const int dense = [] { const char *e = getenv("DFGNN_DENSE"); return e ? atoi(e) : 1; }();
   return dispatch_vec4(g.f, [&](auto cfg) {
     using C = decltype(cfg);
     if (attn_edge) {
       if (int rc = set_max_lds(gt_block_fwd_kernel<C, true>)) return rc;
-      gt_block_fwd_kernel<C, true><<<grid, kBlockThreads, lds, s>>>(g, p.fit(), Q, K, V, attn_edge, edge_ws, out,
-                                                                     (int)lds, dense);
+      gt_block_fwd_kernel<C, true><<<grid, kBlockThreads, lds, s>>>(g, fit, Q, K, V, attn_edge, edge_ws, out,
+                                                                     (int)lds);
     } else {
       if (int rc = set_max_lds(gt_block_fwd_kernel<C, false>)) return rc;
-      gt_block_fwd_kernel<C, false><<<grid, kBlockThreads, lds, s>>>(g, p.fit(), Q, K, V, nullptr, edge_ws, out,
-                                                                      (int)lds, dense);
+      gt_block_fwd_kernel<C, false><<<grid, kBlockThreads, lds, s>>>(g, fit, Q, K, V, nullptr, edge_ws, out,
+                                                                      (int)lds);
     }
     return launch_status();
   });

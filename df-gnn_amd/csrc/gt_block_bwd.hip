@@ -24,6 +24,7 @@ __device__ unsigned long long *dfgnn_bwd_stamps = nullptr;
 #define DFGNN_BSTAMP(k)
 #endif
 
+
 struct BwdLds {
   float *res;              // [n * F]   resident rows: V, K, dO, Q in turn
   float *lw;               // [ne]      dP, then dS * val  (CSR order)
@@ -65,7 +66,7 @@ __global__ __launch_bounds__(kBlockThreads) void gt_block_bwd_kernel(
   constexpr int G = C::G, EPW = C::EPW, F = C::G * C::VEC * C::NCH;
   const int n0 = fit[2 * blockIdx.x], n1raw = fit[2 * blockIdx.x + 1];
   const bool edge_global = (n1raw & kPlanEdgeGlobal) != 0;
-  const int n1 = n1raw & ~kPlanEdgeGlobal;
+  const int n1 = n1raw & kPlanRangeMask;
   const int n = n1 - n0;
   const int head = blockIdx.y;
   const size_t hf = (size_t)g.h * F;
@@ -244,16 +245,23 @@ __global__ __launch_bounds__(kBlockThreads) void gt_block_bwd_kernel(
   DFGNN_BSTAMP(11)
 }
 
+bool dense_enabled();  // gt_block.hip
+
 int launch_gt_block_bwd(const Csr &g, const Plan &p, const int *col_ptr, const int *row_ind, const int *val_idx,
                         const float *Q, const float *K, const float *V, const float *attn_edge,
                         const float *grad_out, float *edge_ws, float *dQ, float *dK, float *dV, hipStream_t s) {
   if (p.num_fit == 0) return 0;
+  const int first = (!g.val && g.rows && dense_enabled()) ? p.num_dense : 0;  // matrix-core kernel, gt_dense.hip
+  if (first > 0)
+    if (int rc = launch_gt_dense_bwd(g, p, Q, K, V, attn_edge, grad_out, dQ, dK, dV, s)) return rc;
+  if (first == p.num_fit) return 0;
   if (p.num_edge_global > 0 && !edge_ws) return kErrBadArg;
-  const dim3 grid(p.num_fit, g.h);
+  const dim3 grid(p.num_fit - first, g.h);
+  const int *fit = p.fit() + 2 * (size_t)first;
   return dispatch_vec4(g.f, [&](auto cfg) {
     using C = decltype(cfg);
     if (int rc = set_max_lds(gt_block_bwd_kernel<C>)) return rc;
-    gt_block_bwd_kernel<C><<<grid, kBlockThreads, kLdsBytes, s>>>(g, p.fit(), col_ptr, row_ind, val_idx, Q, K, V,
+    gt_block_bwd_kernel<C><<<grid, kBlockThreads, kLdsBytes, s>>>(g, fit, col_ptr, row_ind, val_idx, Q, K, V,
                                                                   attn_edge, grad_out, edge_ws, dQ, dK, dV);
     return launch_status();
   });

@@ -1,0 +1,553 @@
+// gt_dense.hip -- matrix-core GT forward and backward for the dense ranges of a block plan.
+//
+// One workgroup of 8 waves per (dense range, head); wave w owns the 16-row strip w (and strip w + 8 of a range
+// with more than 128 nodes).  See dfgnn_dense.hpp for the numerics and the operand layouts.  These kernels replace,
+// for such ranges, the same reference kernels as gt_block.hip / gt_block_bwd.hip (fused_gtconv_hyper.cu:228-560,
+// fused_gtconv_backward.cu:40-191): the dot products, the softmax and the weighted sums of a whole member graph
+// are done as masked dense attention on v_mfma_f32_16x16x32_bf16.
+//
+// Forward:   S^T = K Q^T  ->  masked row softmax in registers  ->  O^T = V^T P^T
+//            The mask is a byte map [i][j] -> position of edge (i, j) in row i (0xFF: no edge), built once per
+//            range in LDS from the CSR arrays; it also tells where P_ij goes in attn_edge.
+// Backward:  P (attn_edge) is scattered into a dense fp32 tile; off-edge pairs have P = 0, hence dS = 0: no mask.
+//            dP^T = V dO^T ;  t_i = sum_j P_ij dP_ij ;  dS = P o (dP - t)        (registers)
+//            dV^T = dO^T P ,  dQ^T = K^T dS^T ,  dK^T = Q^T dS                   (P / dS through a bf16 tile in LDS)
+//            A row block of 128 rows keeps dP / P / dS of all (one or two) 128-column blocks in registers, so t_i
+//            needs no extra sweep and dQ accumulates in registers; dK / dV of a two-block range are accumulated
+//            across the row blocks by the lane that wrote them.
+// LDS: one feature image (K then V; V, dO, K, Q in turn; 72 KB) + the byte map (forward) or one 128 x 136-float
+// tile (backward: P as fp32, then P and dS as interleaved bf16 hi | lo rows, 68 KB).  The next image's global
+// loads are issued one phase ahead into registers, so a phase change costs a barrier and an LDS store.
+#include <type_traits>
+
+#include "dfgnn_dense.hpp"
+
+namespace dfgnn {
+
+#ifdef DFGNN_STAMPS
+__device__ unsigned long long *dfgnn_dense_stamps = nullptr;  // [wg][16] phase boundaries (diagnostic build only)
+#define DFGNN_DSTAMP(k)                                                                             \
+  if (threadIdx.x == 0 && dfgnn_dense_stamps)                                                       \
+    dfgnn_dense_stamps[((size_t)blockIdx.x * gridDim.y + blockIdx.y) * 16 + (k)] = __builtin_amdgcn_s_memtime();
+#else
+#define DFGNN_DSTAMP(k)
+#endif
+
+// =====================================================================================================================
+// forward
+// =====================================================================================================================
+template <int F, bool WRITE_ATTN, int NS>
+__device__ __forceinline__ void dense_fwd_body(float *lds, int lds_bytes, const Csr &g, int n0, int n, int e0, int ne,
+                                               int head, const float *__restrict__ Q, const float *__restrict__ K,
+                                               const float *__restrict__ V, float *__restrict__ attn_edge,
+                                               float *__restrict__ out) {
+  using D = DenseCfg<F>;
+  constexpr int RS = D::RS, KT = D::KT, FT = D::FT, NT = 8 * NS, CR = kDenseChunkRows;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+  const int npad = (n + 31) & ~31, ntile = npad >> 4, nstrip = (n + 15) >> 4;
+  const int MS = npad + 4;
+  __bf16 *ihi = reinterpret_cast<__bf16 *>(lds), *ilo = ihi + (size_t)CR * RS;
+  unsigned char *map = reinterpret_cast<unsigned char *>(ilo + (size_t)CR * RS);
+  const int map_bytes = nstrip * 16 * MS;
+  int *rp = reinterpret_cast<int *>(map + ((map_bytes + 15) & ~15));
+  float *pstage = reinterpret_cast<float *>(rp + ((n + 4) & ~3));  // [ne] normalised attention values, if it fits
+  const size_t fixed_bytes = (size_t)(reinterpret_cast<char *>(pstage) - reinterpret_cast<char *>(lds));
+  const bool stage_attn = WRITE_ATTN && fixed_bytes + (size_t)ne * 4 <= (size_t)lds_bytes;
+  const size_t hf = (size_t)g.h * F, hoff = (size_t)head * F;
+  const float *Qb = Q + (size_t)n0 * hf + hoff, *Kb = K + (size_t)n0 * hf + hoff, *Vb = V + (size_t)n0 * hf + hoff;
+  float *Ob = out + (size_t)n0 * hf + hoff;
+
+  DFGNN_DSTAMP(0)
+  // ---- every long-latency load of the prologue goes out before the first barrier --------------------------------------
+  int pre_i[kDensePre], pre_j[kDensePre];
+  {
+    const int tid = opaque_tid();
+#pragma unroll
+    for (int k = 0; k < kDensePre; ++k) {
+      const unsigned e = (unsigned)min(tid + k * kDenseThreads, ne - 1);  // clamped: plain loads
+      pre_i[k] = ld32(g.rows + e0, e);
+      pre_j[k] = ld32(g.col_ind + e0, e);
+    }
+  }
+  DenseStageRegs<F> st;
+  dense_stage_load<F>(st, Kb, hf, 0, n);
+  bf16x8 qh[NS][KT], ql[NS][KT];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    const LaneIds L = lane_ids();
+    const int i = (wave + 8 * s) * 16 + L.mi;
+    dense_row_operand<F>(qh[s], ql[s], Qb, hf, min(i, n - 1), i < n, L);
+  }
+  {
+    const int tid = opaque_tid();
+    for (int k = tid; k < (map_bytes >> 2); k += kDenseThreads) reinterpret_cast<unsigned *>(map)[k] = 0xFFFFFFFFu;
+    for (int k = tid; k <= n; k += kDenseThreads) rp[k] = g.row_ptr[n0 + k] - e0;
+  }
+  dense_stage_store<F>(st, ihi, ilo);
+  __syncthreads();
+  {  // byte map: position of every edge within its row (the plan guarantees distinct columns and rows < 255 long)
+    const int tid = opaque_tid();
+#pragma unroll
+    for (int k = 0; k < kDensePre; ++k) {
+      const int e = tid + k * kDenseThreads;
+      if (e < ne) {
+        const int i = pre_i[k] - n0, j = pre_j[k] - n0;
+        map[i * MS + j] = (unsigned char)(e - rp[i]);
+      }
+    }
+    for (int e = tid + kDensePre * kDenseThreads; e < ne; e += kDenseThreads) {
+      const int i = g.rows[e0 + e] - n0, j = g.col_ind[e0 + e] - n0;
+      map[i * MS + j] = (unsigned char)(e - rp[i]);
+    }
+  }
+  __syncthreads();
+  DFGNN_DSTAMP(1)
+  if (NS == 1) dense_stage_load<F>(st, Vb, hf, 0, n);  // lands during the S phase
+
+  // ---- S^T = K Q^T -------------------------------------------------------------------------------------------------------
+  f32x4 S[NS][NT];
+#pragma unroll
+  for (int c = 0; c < NS; ++c) {
+    if (c > 0) {
+      __syncthreads();
+      dense_stage_load<F>(st, Kb, hf, c * CR, n);
+      dense_stage_store<F>(st, ihi, ilo);
+      __syncthreads();
+    }
+    const LaneIds L = lane_ids();
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      if (wave + 8 * s < nstrip) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int jt = 8 * c + u;
+          S[s][jt] = (jt < ntile) ? dense_rows_mma<F>(ihi, ilo, u, qh[s], ql[s], L) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+      }
+    }
+  }
+  DFGNN_DSTAMP(2)
+
+  // ---- masked row softmax, in registers -------------------------------------------------------------------------------
+  float inv[NS];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    inv[s] = 0.f;
+    const int strip = wave + 8 * s;
+    if (strip < nstrip) {
+      const LaneIds L = lane_ids();
+      const int i = strip * 16 + L.mi;
+      const unsigned char *mrow = map + i * MS + 4 * L.mq;
+      float mx = -INFINITY;
+#pragma unroll
+      for (int jt = 0; jt < NT; ++jt) {
+        const unsigned w = (jt < ntile) ? *reinterpret_cast<const unsigned *>(mrow + 16 * jt) : 0xFFFFFFFFu;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const bool edge = ((w >> (8 * r)) & 0xFFu) != 0xFFu;
+          const float x = edge ? S[s][jt][r] : -INFINITY;
+          S[s][jt][r] = x;
+          mx = fmaxf(mx, x);
+        }
+      }
+      mx = xor16_32_max(mx);
+      const float base = (mx == -INFINITY) ? 0.f : mx;
+      float sum = 0.f;
+#pragma unroll
+      for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float p = fast_exp(S[s][jt][r] - base);  // exp(-inf) = 0 for the masked pairs
+          S[s][jt][r] = p;
+          sum += p;
+        }
+      sum = xor16_32_sum(sum);
+      inv[s] = (sum != 0.f) ? 1.f / sum : 0.f;
+      if constexpr (WRITE_ATTN) {
+        // attn_edge (CSR order): through LDS when the range's edge array fits (then the strip streams its own
+        // contiguous slice out), else straight from the registers (scattered 4-byte stores)
+        if (i < n) {
+          float *lrow = pstage + rp[i];
+          float *grow = attn_edge + (size_t)head * g.nnz + e0 + rp[i];
+#pragma unroll
+          for (int jt = 0; jt < NT; ++jt) {
+            if (jt < ntile) {
+              const unsigned w = *reinterpret_cast<const unsigned *>(mrow + 16 * jt);
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const unsigned slot = (w >> (8 * r)) & 0xFFu;
+                if (slot != 0xFFu) {
+                  if (stage_attn) lrow[slot] = S[s][jt][r] * inv[s];
+                  else grow[slot] = S[s][jt][r] * inv[s];
+                }
+              }
+            }
+          }
+        }
+        if (stage_attn) {
+          wave_sync();
+          const int s0 = rp[strip * 16], s1 = rp[min(n, strip * 16 + 16)];
+          float *dst = attn_edge + (size_t)head * g.nnz + e0;
+          for (int e = s0 + (int)(threadIdx.x & (kWave - 1)); e < s1; e += kWave) dst[e] = pstage[e];
+        }
+      }
+    }
+  }
+  DFGNN_DSTAMP(3)
+
+  // ---- O^T = V^T P^T --------------------------------------------------------------------------------------------------
+  f32x4 o[NS][FT];
+#pragma unroll
+  for (int s = 0; s < NS; ++s)
+#pragma unroll
+    for (int ft = 0; ft < FT; ++ft) o[s][ft] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int c = 0; c < NS; ++c) {
+    __syncthreads();  // every strip is done with the previous image
+    if (NS > 1 || c > 0) dense_stage_load<F>(st, Vb, hf, c * CR, n);
+    dense_stage_store<F>(st, ihi, ilo);
+    __syncthreads();
+    if (c == 0) { DFGNN_DSTAMP(4) }
+    const LaneIds L = lane_ids();
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      if (wave + 8 * s < nstrip) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int jb = 4 * c + u;  // 32-column block of P
+          if (2 * jb < ntile) dense_cols_mma<F>(o[s], ihi, ilo, u, S[s][2 * jb], S[s][2 * jb + 1], L);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    const LaneIds L = lane_ids();
+    const int i = (wave + 8 * s) * 16 + L.mi;
+    if (i < n) dense_store_acc<FT>(o[s], inv[s], Ob, (unsigned)i * (unsigned)hf + 4u * L.mq, false);
+  }
+  DFGNN_DSTAMP(5)
+  DFGNN_DSTAMP(6)
+}
+
+template <int F, bool WRITE_ATTN>
+__global__ __launch_bounds__(kDenseThreads) void gt_dense_fwd_kernel(Csr g, const int *__restrict__ fit,
+                                                                     const float *__restrict__ Q,
+                                                                     const float *__restrict__ K,
+                                                                     const float *__restrict__ V,
+                                                                     float *__restrict__ attn_edge,
+                                                                     float *__restrict__ out, int lds_bytes) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int n0 = fit[2 * blockIdx.x], n1 = fit[2 * blockIdx.x + 1] & kPlanRangeMask;
+  const int n = n1 - n0, e0 = g.row_ptr[n0], ne = g.row_ptr[n1] - e0;
+  if (n <= kDenseChunkRows)
+    dense_fwd_body<F, WRITE_ATTN, 1>(lds, lds_bytes, g, n0, n, e0, ne, blockIdx.y, Q, K, V, attn_edge, out);
+  else
+    dense_fwd_body<F, WRITE_ATTN, 2>(lds, lds_bytes, g, n0, n, e0, ne, blockIdx.y, Q, K, V, attn_edge, out);
+#ifdef DFGNN_STAMPS
+  if (threadIdx.x == 0 && dfgnn_dense_stamps)
+    dfgnn_dense_stamps[((size_t)blockIdx.x * gridDim.y + blockIdx.y) * 16 + 15] = ((unsigned long long)n << 32) | (unsigned)ne;
+#endif
+}
+
+// =====================================================================================================================
+// backward
+// =====================================================================================================================
+constexpr int kDenseTileStride = 136;  // floats per tile row == 2 x 136 bf16 (hi | lo)
+
+template <int F, int NBLK>
+__device__ __forceinline__ void dense_bwd_body(float *lds, const Csr &g, int n0, int n, int e0, int ne, int head,
+                                               const float *__restrict__ Q, const float *__restrict__ K,
+                                               const float *__restrict__ V, const float *__restrict__ attn_edge,
+                                               const float *__restrict__ dO, float *__restrict__ dQ,
+                                               float *__restrict__ dK, float *__restrict__ dV) {
+  using D = DenseCfg<F>;
+  constexpr int RS = D::RS, KT = D::KT, FT = D::FT, CR = kDenseChunkRows, TS = kDenseTileStride;
+  constexpr int TB = 2 * TS;                   // bf16 elements per interleaved tile row: hi at +0, lo at +TS
+  constexpr int PRE = NBLK == 1 ? kDensePre : kDensePre / 4;  // two column blocks leave few registers
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);  // = this wave's strip of a 128-row block
+  __bf16 *ihi = reinterpret_cast<__bf16 *>(lds), *ilo = ihi + (size_t)CR * RS;
+  float *T = reinterpret_cast<float *>(ilo + (size_t)CR * RS);
+  __bf16 *Tb = reinterpret_cast<__bf16 *>(T);
+  const size_t hf = (size_t)g.h * F, hoff = (size_t)head * F;
+  const float *Qb = Q + (size_t)n0 * hf + hoff, *Kb = K + (size_t)n0 * hf + hoff, *Vb = V + (size_t)n0 * hf + hoff,
+              *dOb = dO + (size_t)n0 * hf + hoff;
+  float *dQb = dQ + (size_t)n0 * hf + hoff, *dKb = dK + (size_t)n0 * hf + hoff, *dVb = dV + (size_t)n0 * hf + hoff;
+  const float *attn_h = attn_edge + (size_t)head * g.nnz;
+  const int emid = (NBLK > 1) ? g.row_ptr[n0 + CR] : 0;  // first edge of row block 1
+
+  DFGNN_DSTAMP(0)
+  // The image that is needed next is fetched one phase ahead into registers (`st`) -- for a single-block range; with
+  // two column blocks the registers hold dP / P / dS of both and the image is fetched where it is stored.
+  DenseStageRegs<F> st;
+  const float *next_src = nullptr;
+  int next_row0 = 0;
+  auto image_prefetch = [&](const float *src, int row0) {
+    if (NBLK == 1) {
+      dense_stage_load<F>(st, src, hf, row0, n);
+    } else {
+      next_src = src;
+      next_row0 = row0;
+    }
+  };
+  auto image_commit = [&]() {
+    if (NBLK > 1) dense_stage_load<F>(st, next_src, hf, next_row0, n);
+    dense_stage_store<F>(st, ihi, ilo);
+  };
+  // the first PRE edges per thread of the current row block, fetched ahead of the tiles that scatter them
+  int pi[PRE], pj[PRE];
+  float pa[PRE];
+  auto edge_range = [&](int i0, int &ea, int &eb) {
+    ea = (i0 == 0) ? e0 : emid;
+    eb = (i0 == 0 && NBLK > 1) ? emid : e0 + ne;
+  };
+  auto prefetch_edges = [&](int i0) {
+    int ea, eb;
+    edge_range(i0, ea, eb);
+    const int tid = opaque_tid();
+#pragma unroll
+    for (int k = 0; k < PRE; ++k) {
+      const unsigned e = (unsigned)min(tid + k * kDenseThreads, eb - ea - 1);  // clamped: plain loads
+      pi[k] = ld32(g.rows + ea, e);
+      pj[k] = ld32(g.col_ind + ea, e);
+      pa[k] = ld32(attn_h + ea, e);
+    }
+  };
+  // Zero the tile, put the prefetched V image into LDS, scatter P of tile (i0, j0) into the tile (fp32).
+  auto load_tile = [&](int i0, int j0) {
+    int ea, eb;
+    edge_range(i0, ea, eb);
+    const int tid = opaque_tid();
+    for (int k = tid; k < CR * TS / 4; k += kDenseThreads)
+      reinterpret_cast<float4 *>(T)[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    image_commit();
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < PRE; ++k) {
+      const int j = pj[k] - n0 - j0;
+      if (tid + k * kDenseThreads < eb - ea && j >= 0 && j < CR) T[(pi[k] - n0 - i0) * TS + j] = pa[k];
+    }
+    for (int e = ea + tid + PRE * kDenseThreads; e < eb; e += kDenseThreads) {
+      const int i = g.rows[e] - n0 - i0, j = g.col_ind[e] - n0 - j0;
+      if (j >= 0 && j < CR) T[i * TS + j] = attn_h[e];
+    }
+    __syncthreads();
+  };
+  // this strip's 16 x 128 values -> its own rows of the tile, as interleaved bf16 hi | lo halves
+  auto strip_to_tile = [&](const f32x4 (&X)[8]) {
+    const LaneIds L = lane_ids();
+    __bf16 *trow = Tb + (wave * 16 + L.mi) * TB + 4 * L.mq;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      bf16x4 h4, l4;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const __bf16 h = (__bf16)X[u][r];
+        h4[r] = h;
+        l4[r] = (__bf16)(X[u][r] - (float)h);
+      }
+      *reinterpret_cast<bf16x4 *>(trow + 16 * u) = h4;
+      *reinterpret_cast<bf16x4 *>(trow + TS + 16 * u) = l4;
+    }
+  };
+  // out^T[f][c] = sum_i X[i][f] Y[i][c]: X = the image (ni rows), Y = the bf16 tile, c = this wave's 16 columns
+  // (rows j0 + 16 wave .. of the output)
+  auto column_phase = [&](float *outb, int j0, int ni, bool accumulate) {
+    const LaneIds L = lane_ids();
+    const int j = j0 + wave * 16 + L.mi;
+    f32x4 acc[FT];
+#pragma unroll
+    for (int ft = 0; ft < FT; ++ft) acc[ft] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ib = 0; ib < 4; ++ib) {
+      if (32 * ib < ni) {
+        const int yoff = (32 * ib + 4 * L.mq + L.tq) * TB + 16 * wave + 4 * L.tp;
+        const bf16x8 yh = dense_tr_pair(Tb + yoff, 16 * TB);
+        const bf16x8 yl = dense_tr_pair(Tb + yoff + TS, 16 * TB);
+        dense_kblock_mma<F>(acc, ihi, ilo, (32 * ib + 4 * L.mq + L.tq) * RS + 4 * L.tp, 16 * RS, yh, yl);
+      }
+    }
+    if (j < n) dense_store_acc<FT>(acc, 1.f, outb, (unsigned)j * (unsigned)hf + 4u * L.mq, accumulate);
+  };
+
+  prefetch_edges(0);
+  image_prefetch(Vb, 0);
+  for (int ic = 0; ic < NBLK; ++ic) {
+    const int i0 = ic * CR, ni = min(n - i0, CR);
+    const bool row_wave = wave * 16 < ni;
+
+    // ---- dP for every column block, t, dS ---------------------------------------------------------------------------
+    f32x4 dS[NBLK][8], Pr[NBLK][8];
+    {
+      bf16x8 gh[KT], gl[KT];
+      {
+        const LaneIds L = lane_ids();
+        const int i = i0 + wave * 16 + L.mi;
+        dense_row_operand<F>(gh, gl, dOb, hf, min(i, n - 1), i < n, L);
+      }
+#pragma unroll
+      for (int jc = 0; jc < NBLK; ++jc) {
+        load_tile(i0, jc * CR);  // image = V rows of column block jc, tile = P (fp32)
+        DFGNN_DSTAMP(9)
+        if (jc + 1 < NBLK) image_prefetch(Vb, (jc + 1) * CR);
+        else image_prefetch(dOb, i0);  // next image: dO rows i0..
+        if (row_wave) {
+          const LaneIds L = lane_ids();
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            dS[jc][u] = dense_rows_mma<F>(ihi, ilo, u, gh, gl, L);  // dP for now
+            const float4 p = *reinterpret_cast<const float4 *>(T + (wave * 16 + L.mi) * TS + 16 * u + 4 * L.mq);
+            Pr[jc][u] = f32x4{p.x, p.y, p.z, p.w};
+          }
+        }
+        if (jc + 1 < NBLK) __syncthreads();  // the next tile overwrites the image and the tile
+      }
+    }
+    DFGNN_DSTAMP(1)
+    if (row_wave) {
+      float t = 0.f;
+#pragma unroll
+      for (int jc = 0; jc < NBLK; ++jc)
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) t = fmaf(Pr[jc][u][r], dS[jc][u][r], t);
+      t = xor16_32_sum(t);  // a row lives on 4 lanes of this wave
+#pragma unroll
+      for (int jc = 0; jc < NBLK; ++jc)
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) dS[jc][u][r] = Pr[jc][u][r] * (dS[jc][u][r] - t);
+    }
+    DFGNN_DSTAMP(2)
+
+    // ---- dV^T = dO^T P, column block by column block (last first: its fp32 tile has just been consumed) -----------------
+#pragma unroll
+    for (int jj = 0; jj < NBLK; ++jj) {
+      const int jc = NBLK - 1 - jj, j0 = jc * CR;
+      if (row_wave) strip_to_tile(Pr[jc]);  // own rows only
+      if (jj == 0) {
+        __syncthreads();  // every strip is done with the V image
+        image_commit();
+        image_prefetch(Kb, 0);  // next image: K rows 0..
+      }
+      __syncthreads();
+      DFGNN_DSTAMP(3)
+      if (wave * 16 < n - j0) column_phase(dVb, j0, ni, ic > 0);
+      __syncthreads();  // tile free (and, after the last block, the dO image)
+    }
+    DFGNN_DSTAMP(4)
+
+    // ---- dQ^T = K^T dS^T (accumulated over the column blocks in registers) and dK^T = Q^T dS ---------------------------
+    f32x4 qacc[FT];
+#pragma unroll
+    for (int ft = 0; ft < FT; ++ft) qacc[ft] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int jc = 0; jc < NBLK; ++jc) {
+      const int j0 = jc * CR, nj = min(n - j0, CR);
+      if (row_wave) strip_to_tile(dS[jc]);
+      image_commit();             // K rows j0..
+      image_prefetch(Qb, i0);     // next image: Q rows i0..
+      __syncthreads();
+      DFGNN_DSTAMP(5)
+      if (row_wave) {
+        const LaneIds L = lane_ids();
+        const __bf16 *srow = Tb + (wave * 16 + L.mi) * TB + 8 * L.mq;
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb) {
+          if (32 * jb < nj) {
+            // natural k order: element t of lane (mi, mq) is column 32 jb + 8 mq + t of dS / that row of K
+            const bf16x8 sh = *reinterpret_cast<const bf16x8 *>(srow + 32 * jb);
+            const bf16x8 sl = *reinterpret_cast<const bf16x8 *>(srow + TS + 32 * jb);
+            dense_kblock_mma<F>(qacc, ihi, ilo, (32 * jb + 8 * L.mq + L.tq) * RS + 4 * L.tp, 4 * RS, sh, sl);
+          }
+        }
+      }
+      DFGNN_DSTAMP(6)
+      __syncthreads();  // K image free
+      image_commit();  // Q rows i0..
+      if (jc + 1 < NBLK) {
+        image_prefetch(Kb, (jc + 1) * CR);
+      } else if (ic + 1 < NBLK) {  // the next row block starts with its edges and V rows 0..
+        prefetch_edges(i0 + CR);
+        image_prefetch(Vb, 0);
+      }
+      __syncthreads();
+      DFGNN_DSTAMP(7)
+      if (wave * 16 < nj) column_phase(dKb, j0, ni, ic > 0);
+      __syncthreads();  // Q image and dS tile free
+    }
+    if (row_wave) {
+      const LaneIds L = lane_ids();
+      const int i = i0 + wave * 16 + L.mi;
+      if (i < n) dense_store_acc<FT>(qacc, 1.f, dQb, (unsigned)i * (unsigned)hf + 4u * L.mq, false);
+    }
+    DFGNN_DSTAMP(8)
+  }
+}
+
+template <int F>
+__global__ __launch_bounds__(kDenseThreads) void gt_dense_bwd_kernel(
+    Csr g, const int *__restrict__ fit, const float *__restrict__ Q, const float *__restrict__ K,
+    const float *__restrict__ V, const float *__restrict__ attn_edge, const float *__restrict__ dO,
+    float *__restrict__ dQ, float *__restrict__ dK, float *__restrict__ dV) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int n0 = fit[2 * blockIdx.x], n1 = fit[2 * blockIdx.x + 1] & kPlanRangeMask;
+  const int n = n1 - n0, e0 = g.row_ptr[n0], ne = g.row_ptr[n1] - e0;
+  if (n <= kDenseChunkRows) dense_bwd_body<F, 1>(lds, g, n0, n, e0, ne, blockIdx.y, Q, K, V, attn_edge, dO, dQ, dK, dV);
+  else dense_bwd_body<F, 2>(lds, g, n0, n, e0, ne, blockIdx.y, Q, K, V, attn_edge, dO, dQ, dK, dV);
+#ifdef DFGNN_STAMPS
+  if (threadIdx.x == 0 && dfgnn_dense_stamps)
+    dfgnn_dense_stamps[((size_t)blockIdx.x * gridDim.y + blockIdx.y) * 16 + 15] = ((unsigned long long)n << 32) | (unsigned)ne;
+#endif
+}
+
+// =====================================================================================================================
+// launchers: the first p.num_dense entries of the plan's fit list
+// =====================================================================================================================
+template <class Fn>
+static int dispatch_dense(int f, Fn &&fn) {
+  if (f == 32) return fn(std::integral_constant<int, 32>{});
+  if (f == 64) return fn(std::integral_constant<int, 64>{});
+  if (f == 128) return fn(std::integral_constant<int, 128>{});
+  return kErrUnsupported;
+}
+
+int launch_gt_dense_fwd(const Csr &g, const Plan &p, const float *Q, const float *K, const float *V,
+                        float *attn_edge, float *out, hipStream_t s) {
+  if (p.num_dense == 0) return 0;
+  const dim3 grid(p.num_dense, g.h);
+  return dispatch_dense(g.f, [&](auto fc) {
+    constexpr int F = decltype(fc)::value;
+    if (attn_edge) {
+      if (int rc = set_max_lds(gt_dense_fwd_kernel<F, true>)) return rc;
+      gt_dense_fwd_kernel<F, true><<<grid, kDenseThreads, kLdsBytes, s>>>(g, p.fit(), Q, K, V, attn_edge, out, kLdsBytes);
+    } else {
+      if (int rc = set_max_lds(gt_dense_fwd_kernel<F, false>)) return rc;
+      gt_dense_fwd_kernel<F, false><<<grid, kDenseThreads, kLdsBytes, s>>>(g, p.fit(), Q, K, V, nullptr, out, kLdsBytes);
+    }
+    return launch_status();
+  });
+}
+
+int launch_gt_dense_bwd(const Csr &g, const Plan &p, const float *Q, const float *K, const float *V,
+                        const float *attn_edge, const float *grad_out, float *dQ, float *dK, float *dV,
+                        hipStream_t s) {
+  if (p.num_dense == 0) return 0;
+  const dim3 grid(p.num_dense, g.h);
+  return dispatch_dense(g.f, [&](auto fc) {
+    constexpr int F = decltype(fc)::value;
+    if (int rc = set_max_lds(gt_dense_bwd_kernel<F>)) return rc;
+    gt_dense_bwd_kernel<F><<<grid, kDenseThreads, kLdsBytes, s>>>(g, p.fit(), Q, K, V, attn_edge, grad_out, dQ, dK, dV);
+    return launch_status();
+  });
+}
+
+}  // namespace dfgnn
+
+#ifdef DFGNN_STAMPS
+extern "C" int dfgnn_debug_set_dense_stamps(void *p) {
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(dfgnn::dfgnn_dense_stamps), &p, sizeof(p));
+}
+#endif

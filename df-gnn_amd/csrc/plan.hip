@@ -12,10 +12,15 @@
 //
 // Plan buffer (int32, device), sized by dfgnn_plan_ints(m):
 //   [0 .. 12)           header: num_fit, num_spill, max_fit_nodes, max_fit_edges, m, nnz, f, budget,
-//                               num_edge_global (fit ranges whose per-edge fp32 array lives in global scratch), 0, 0, 0
-//   [12 .. 12+2m)       fit ranges   (n0, n1 | kPlanEdgeGlobal) pairs
+//                               num_edge_global (fit ranges whose per-edge fp32 array lives in global scratch),
+//                               num_dense (fit ranges that qualify for the matrix-core kernels; they come first), 0, 0
+//   [12 .. 12+2m)       fit ranges   (n0, n1 | kPlanEdgeGlobal | kPlanDense) pairs: dense ones first, each group
+//                                    largest first
 //   [12+2m .. 12+4m)    spill chunks (r0, r1) pairs, r1 - r0 <= kHyperRows
-//   [12+4m .. )         scratch: lo[m], hi[m], bounds[m+1]
+//   [12+4m .. )         scratch: lo[m], hi[m], bounds[m+1], unsorted[m+1]
+//
+// "Dense" (gt_dense.hip, dfgnn_dense.hpp): at most 255 nodes, at least one edge per 32 node pairs, f in {32, 64, 128}
+// and no duplicate edge in any row of the range -- the one thing a dense mask cannot represent.
 #include "../../include/dfgnn.h"
 #include "dfgnn_launch.hpp"
 
@@ -24,17 +29,37 @@ namespace dfgnn {
 constexpr int kPlanThreads = 1024;
 
 __global__ void plan_row_extent_kernel(int m, const int *__restrict__ row_ptr, const int *__restrict__ col_ind,
-                                       int *__restrict__ lo, int *__restrict__ hi) {
+                                       int *__restrict__ lo, int *__restrict__ hi, int *__restrict__ unsorted) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= m) return;
-  int l = i, h = i;
-  for (int e = row_ptr[i]; e < row_ptr[i + 1]; ++e) {
+  const int ea = row_ptr[i], eb = row_ptr[i + 1];
+  int cl = i, ch = i;
+  for (int e = ea; e < eb; ++e) {
     const int c = col_ind[e];
-    l = min(l, c);
-    h = max(h, c);
+    cl = min(cl, c);
+    ch = max(ch, c);
   }
-  lo[i] = l;
-  hi[i] = h;
+  lo[i] = cl;
+  hi[i] = ch;
+  // Duplicate columns in the row?  Only rows that could sit in a dense range matter (the range holds cl .. ch, so
+  // its span and its length are below 256): those are checked against a 256-bit map of the columns seen so far.
+  int bad = 1;
+  if (ch - cl < 256 && eb - ea < 256) {
+    unsigned long long w0 = 0, w1 = 0, w2 = 0, w3 = 0;
+    bad = 0;
+    for (int e = ea; e < eb; ++e) {
+      const int k = col_ind[e] - cl;
+      const unsigned long long bit = 1ull << (k & 63);
+      const int q = k >> 6;
+      const unsigned long long cur = q == 0 ? w0 : q == 1 ? w1 : q == 2 ? w2 : w3;
+      bad |= (cur & bit) ? 1 : 0;
+      w0 |= q == 0 ? bit : 0;
+      w1 |= q == 1 ? bit : 0;
+      w2 |= q == 2 ? bit : 0;
+      w3 |= q == 3 ? bit : 0;
+    }
+  }
+  unsorted[i] = bad;  // 1: the row has a duplicate edge (or is too wide / long to be part of a dense range)
 }
 
 // Exclusive scan of part[0 .. kPlanThreads) in place by wave 0 (lane l owns 16 consecutive entries, a wave-level
@@ -82,6 +107,7 @@ __global__ __launch_bounds__(kPlanThreads) void plan_cut_kernel(int m, int nnz, 
   int *lo = spill + 2 * (size_t)m;
   int *hi = lo + m;
   int *bounds = hi + m;  // [m + 1] ends of the natural closed ranges
+  int *unsorted = bounds + m + 1;  // [m + 1] in: per-row 'has a duplicate edge' flag, out: exclusive prefix count
   const int t = threadIdx.x;
   const int chunk = (m + kPlanThreads - 1) / kPlanThreads;
   const int b = min(m, t * chunk), e = min(m, b + chunk);
@@ -102,6 +128,21 @@ __global__ __launch_bounds__(kPlanThreads) void plan_cut_kernel(int m, int nnz, 
   acc = part[t];
   for (int i = e - 1; i >= b; --i) { acc = min(acc, lo[i]); lo[i] = acc; }
   __syncthreads();
+  // exclusive prefix count of the rows with duplicate edges (unsorted[m] = total)
+  {
+    int c = 0;
+    for (int i = b; i < e; ++i) c += unsorted[i];
+    part[t] = c;
+    plan_scan_partials<true>(part, 0, [](int a, int b) { return a + b; });
+    int run = part[t];
+    for (int i = b; i < e; ++i) {
+      const int v = unsorted[i];
+      unsorted[i] = run;
+      run += v;
+    }
+    if (e == m) unsorted[m] = run;  // every thread whose chunk ends at m holds the total
+    __syncthreads();
+  }
   // count boundaries per thread chunk, scan, write
   int cnt = 0;
   for (int i = b; i < e; ++i) cnt += (hi[i] <= i && (i + 1 == m || lo[i + 1] >= i + 1)) ? 1 : 0;
@@ -129,7 +170,8 @@ __global__ __launch_bounds__(kPlanThreads) void plan_cut_kernel(int m, int nnz, 
     }
   __syncthreads();
   if (t == 0) {
-    int nfit = 0, nspill = 0, maxn = 0, maxe = 0, nglobal = 0;
+    int nfit = 0, nspill = 0, maxn = 0, maxe = 0, nglobal = 0, ndense = 0;
+    const bool dense_f = (f == 32 || f == 64 || f == 128);
     // LDS bytes of a range [n0, n1) holding ed edges: resident rows + 1/sum + rebased row_ptr + narrowed
     // column ids, plus (full only) the per-edge fp32 array.  Layout: dfgnn_block.hpp:carve_block_lds.
     auto lite = [&](long n, long ed) -> long { return n * (long)f * 4 + n * 8 + ed * (n <= 256 ? 1 : 2); };
@@ -137,9 +179,12 @@ __global__ __launch_bounds__(kPlanThreads) void plan_cut_kernel(int m, int nnz, 
     auto flush = [&](int n0, int n1, int ed) {
       if (n1 <= n0) return;
       const bool edge_global = full(n1 - n0, ed) > budget_bytes;  // only ever true for an unmerged range
+      const long nn = n1 - n0;
+      const bool dense = dense_f && nn <= 255 && (long)ed * 32 >= nn * nn && unsorted[n1] == unsorted[n0];
       fit[2 * nfit] = n0;
-      fit[2 * nfit + 1] = n1 | (edge_global ? kPlanEdgeGlobal : 0);
+      fit[2 * nfit + 1] = n1 | (edge_global ? kPlanEdgeGlobal : 0) | (dense ? kPlanDense : 0);
       nglobal += edge_global ? 1 : 0;
+      ndense += dense ? 1 : 0;
       ++nfit;
       maxn = max(maxn, n1 - n0);
       maxe = max(maxe, ed);
@@ -188,7 +233,8 @@ __global__ __launch_bounds__(kPlanThreads) void plan_cut_kernel(int m, int nnz, 
     hdr[6] = f;
     hdr[7] = budget_bytes;
     hdr[8] = nglobal;
-    hdr[9] = hdr[10] = hdr[11] = 0;
+    hdr[9] = (nfit <= kCache) ? ndense : 0;  // the dense ranges are only usable once sorted to the front (below)
+    hdr[10] = hdr[11] = 0;
     s_nfit = nfit;
   }
   __syncthreads();
@@ -202,8 +248,9 @@ __global__ __launch_bounds__(kPlanThreads) void plan_cut_kernel(int m, int nnz, 
     while (N < nfit) N <<= 1;
     for (int i = t; i < N; i += kPlanThreads) {
       if (i < nfit) {
-        const int n0 = fit[2 * i], n1 = fit[2 * i + 1] & ~kPlanEdgeGlobal;
-        s_end[i] = row_ptr[n1] - row_ptr[n0];
+        const int n0 = fit[2 * i], n1 = fit[2 * i + 1] & kPlanRangeMask;
+        // key: dense ranges first, then by edge count (a dense range has < 2^16 edges)
+        s_end[i] = ((fit[2 * i + 1] & kPlanDense) ? (1 << 30) : 0) + min(row_ptr[n1] - row_ptr[n0], (1 << 30) - 1);
       } else {
         s_end[i] = -1;
       }
@@ -242,7 +289,7 @@ using namespace dfgnn;
 
 extern "C" {
 
-size_t dfgnn_plan_ints(int m) { return m < 0 ? 0 : kPlanHeader + 7 * (size_t)m + 1; }
+size_t dfgnn_plan_ints(int m) { return m < 0 ? 0 : kPlanHeader + 8 * (size_t)m + 2; }
 
 int dfgnn_plan_build(int m, int nnz, int f, const int *row_ptr, const int *col_ind, int *plan, int *meta_host,
                      dfgnn_stream_t stream) {
@@ -254,7 +301,8 @@ int dfgnn_plan_build(int m, int nnz, int f, const int *row_ptr, const int *col_i
   if (!row_ptr || (nnz > 0 && !col_ind)) return kErrBadArg;
   int *lo = plan + kPlanHeader + 4 * (size_t)m;
   int *hi = lo + m;
-  plan_row_extent_kernel<<<(m + 255) / 256, 256, 0, s>>>(m, row_ptr, col_ind, lo, hi);
+  int *unsorted = hi + m + (m + 1);
+  plan_row_extent_kernel<<<(m + 255) / 256, 256, 0, s>>>(m, row_ptr, col_ind, lo, hi, unsorted);
   if (int rc = launch_status()) return rc;
   plan_cut_kernel<<<1, kPlanThreads, 0, s>>>(m, nnz, f, kBlockLdsBudget, kBlockMergeNodes, row_ptr, plan);
   if (int rc = launch_status()) return rc;

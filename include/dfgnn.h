@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define DFGNN_ABI_VERSION 4
+#define DFGNN_ABI_VERSION 5
 
 #define DFGNN_E_BADARG (-1)      /* negative size / NULL required pointer                      */
 #define DFGNN_E_UNSUPPORTED (-2) /* feature width outside the compiled range (f > 1024, or     */
@@ -52,9 +52,13 @@ const char *dfgnn_error_string(int code);
  * everything else into 16-row chunks for the general kernels.  Results are identical with or
  * without a plan.  The plan depends on the graph structure and on f only; build it once per batch
  * (it belongs to preprocessing, like the reference's preprocess_Hyper, DFGNN/layers/util.py:82-100).
+ * Ranges that are dense (>= 1 edge per 32 node pairs), have at most 255 nodes, f in {32, 64, 128} and no
+ * duplicate edges are additionally marked for the matrix-core kernels, which the GT
+ * forward / backward use for them when val == NULL (unit edge values): masked dense attention on MFMA,
+ * split-bf16 operands with fp32 accumulation (~2^-16 relative error per product).
  *   plan       device buffer of dfgnn_plan_ints(m) int32
  *   meta_host  host buffer of 12 int32 filled on return: num_fit, num_spill, max_fit_nodes,
- *              max_fit_edges, m, nnz, f, lds_budget, num_edge_global, 0, 0, 0
+ *              max_fit_edges, m, nnz, f, lds_budget, num_edge_global, num_dense, 0, 0
  * dfgnn_plan_build synchronises `stream` (it copies the 12 header words back); nothing else in this
  * library does. */
 size_t dfgnn_plan_ints(int m);

@@ -201,11 +201,13 @@ def test_full_size_properties_c3():
     dQ, dK, dV = gt.gt_backward(row_ptr, col_ind, rows, val, col_ptr, row_ind, val_idx, smem, Q, K, V, attn, dO)
     lhs = (dO.double() * out.double()).sum()
     rhs = (dV.double() * V.double()).sum()
-    assert abs(float(lhs - rhs)) <= 1e-5 * max(1.0, abs(float(lhs)))
+    # both sides are cancellation-heavy sums of ~1.8e7 terms: the error bar is relative to the sum of magnitudes
+    # (the matrix-core path carries ~2^-16 per product, the 1e-3 parity bar would allow far more)
+    assert abs(float(lhs - rhs)) <= 1e-6 * float((dO.double() * out.double()).abs().sum())
     # softmax shift invariance: dS sums to zero per row  =>  <dQ, Q> == <dK, K>
     a = (dQ.double() * Q.double()).sum()
     b = (dK.double() * K.double()).sum()
-    assert abs(float(a - b)) <= 1e-4 * max(1.0, abs(float(a)))
+    assert abs(float(a - b)) <= 1e-5 * float((dQ.double() * Q.double()).abs().sum())
 
 
 def test_layers_fused_vs_baseline():
@@ -304,10 +306,18 @@ def test_block_plan_structure():
     nfit, nspill, maxn, maxe = plan.meta[:4]
     buf = plan.buf.cpu().numpy()
     m = g.num_nodes()
-    fit = buf[12:12 + 2 * nfit].reshape(-1, 2) & ~(1 << 30)
+    raw = buf[12:12 + 2 * nfit].reshape(-1, 2)
+    FLAGS = (1 << 30) | (1 << 29)               # per-edge array in global scratch | dense (matrix-core kernels)
+    fit = raw & ~FLAGS
     rp = row_ptr.cpu().numpy()
     edges_in_order = rp[fit[:, 1]] - rp[fit[:, 0]]
-    assert (np.diff(edges_in_order) <= 0).all()                                          # largest ranges first
+    dense = (raw[:, 1] & (1 << 29)) != 0
+    nd = plan.num_dense
+    assert dense[:nd].all() and not dense[nd:].any()                                     # dense ranges come first,
+    assert (np.diff(edges_in_order[:nd]) <= 0).all() and (np.diff(edges_in_order[nd:]) <= 0).all()  # largest first
+    nn = (fit[:, 1] - fit[:, 0]).astype(np.int64)
+    assert (dense == ((nn <= 255) & (32 * edges_in_order >= nn * nn))).all()             # no duplicate edges: all eligible
+    assert nd > 0
     fit = fit[np.argsort(fit[:, 0])]
     ends = _natural_ranges(row_ptr.cpu().numpy(), col_ind.cpu().numpy())
     assert nspill == 0 and nfit >= 1
@@ -318,7 +328,8 @@ def test_block_plan_structure():
     assert maxe == (rp[fit[:, 1]] - rp[fit[:, 0]]).max()
     # f = 16: many graphs merge into one block of <= 256 nodes
     plan16 = build_plan(row_ptr, col_ind, 16)
-    fit16 = plan16.buf.cpu().numpy()[12:12 + 2 * plan16.meta[0]].reshape(-1, 2) & ~(1 << 30)
+    fit16 = plan16.buf.cpu().numpy()[12:12 + 2 * plan16.meta[0]].reshape(-1, 2) & ~FLAGS
+    assert plan16.num_dense == 0                                                         # f = 16 has no matrix-core form
     assert plan16.meta[0] < nfit and (fit16[:, 1] - fit16[:, 0]).max() <= 256
     # a full graph is one closed range that cannot fit: everything spills in <= 16-row chunks
     c = S.cora_like()
