@@ -83,9 +83,9 @@ __device__ __forceinline__ void dense_fwd_body(float *lds, int lds_bytes, const 
     for (int k = tid; k < (map_bytes >> 2); k += kDenseThreads) reinterpret_cast<unsigned *>(map)[k] = 0xFFFFFFFFu;
     for (int k = tid; k <= n; k += kDenseThreads) rp[k] = g.row_ptr[n0 + k] - e0;
   }
-  dense_stage_store<F>(st, ihi, ilo);
   __syncthreads();
-  {  // byte map: position of every edge within its row (the plan guarantees distinct columns and rows < 255 long)
+  {  // byte map: position of every edge within its row (the plan guarantees distinct columns and rows < 255 long);
+     // the edge loads were issued first, so this runs while the K rows are still on their way
     const int tid = opaque_tid();
 #pragma unroll
     for (int k = 0; k < kDensePre; ++k) {
@@ -100,9 +100,12 @@ __device__ __forceinline__ void dense_fwd_body(float *lds, int lds_bytes, const 
       map[i * MS + j] = (unsigned char)(e - rp[i]);
     }
   }
+  dense_stage_store<F>(st, ihi, ilo);
   __syncthreads();
   DFGNN_DSTAMP(1)
-  if (NS == 1) dense_stage_load<F>(st, Vb, hf, 0, n);  // lands during the S phase
+  // the next image (K rows 128.. of a two-chunk range, else V rows 0..) lands during the S phase
+  if (NS == 1) dense_stage_load<F>(st, Vb, hf, 0, n);
+  else dense_stage_load<F>(st, Kb, hf, CR, n);
 
   // ---- S^T = K Q^T -------------------------------------------------------------------------------------------------------
   f32x4 S[NS][NT];
@@ -110,8 +113,8 @@ __device__ __forceinline__ void dense_fwd_body(float *lds, int lds_bytes, const 
   for (int c = 0; c < NS; ++c) {
     if (c > 0) {
       __syncthreads();
-      dense_stage_load<F>(st, Kb, hf, c * CR, n);
       dense_stage_store<F>(st, ihi, ilo);
+      dense_stage_load<F>(st, Vb, hf, 0, n);  // V rows 0.., for the first O^T chunk
       __syncthreads();
     }
     const LaneIds L = lane_ids();
@@ -204,8 +207,8 @@ __device__ __forceinline__ void dense_fwd_body(float *lds, int lds_bytes, const 
 #pragma unroll
   for (int c = 0; c < NS; ++c) {
     __syncthreads();  // every strip is done with the previous image
-    if (NS > 1 || c > 0) dense_stage_load<F>(st, Vb, hf, c * CR, n);
     dense_stage_store<F>(st, ihi, ilo);
+    if (c + 1 < NS) dense_stage_load<F>(st, Vb, hf, (c + 1) * CR, n);
     __syncthreads();
     if (c == 0) { DFGNN_DSTAMP(4) }
     const LaneIds L = lane_ids();
@@ -264,7 +267,6 @@ __device__ __forceinline__ void dense_bwd_body(float *lds, const Csr &g, int n0,
   using D = DenseCfg<F>;
   constexpr int RS = D::RS, KT = D::KT, FT = D::FT, CR = kDenseChunkRows, TS = kDenseTileStride;
   constexpr int TB = 2 * TS;                   // bf16 elements per interleaved tile row: hi at +0, lo at +TS
-  constexpr int PRE = NBLK == 1 ? kDensePre : kDensePre / 4;  // two column blocks leave few registers
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);  // = this wave's strip of a 128-row block
   __bf16 *ihi = reinterpret_cast<__bf16 *>(lds), *ilo = ihi + (size_t)CR * RS;
   float *T = reinterpret_cast<float *>(ilo + (size_t)CR * RS);
@@ -282,55 +284,77 @@ __device__ __forceinline__ void dense_bwd_body(float *lds, const Csr &g, int n0,
   DenseStageRegs<F> st;
   const float *next_src = nullptr;
   int next_row0 = 0;
+  bool next_deferred = false;
   auto image_prefetch = [&](const float *src, int row0) {
-    if (NBLK == 1) {
-      dense_stage_load<F>(st, src, hf, row0, n);
-    } else {
+    const bool defer = NBLK > 1;  // two column blocks: dP / P / dS of both fill the register file
+    next_deferred = defer;
+    if (defer) {
       next_src = src;
       next_row0 = row0;
+    } else {
+      dense_stage_load<F>(st, src, hf, row0, n);
     }
   };
   auto image_commit = [&]() {
-    if (NBLK > 1) dense_stage_load<F>(st, next_src, hf, next_row0, n);
+    if (next_deferred) dense_stage_load<F>(st, next_src, hf, next_row0, n);
     dense_stage_store<F>(st, ihi, ilo);
   };
-  // the first PRE edges per thread of the current row block, fetched ahead of the tiles that scatter them
-  int pi[PRE], pj[PRE];
-  float pa[PRE];
+  // Edges of a row block (CSR order, contiguous) are fetched several per thread at a time -- loads first, then the
+  // scatter into the fp32 tile -- so that a batch costs one memory round trip; the first batch of a range is
+  // fetched ahead of everything else.
+  int pi[kDensePre], pj[kDensePre];
+  float pa[kDensePre];
   auto edge_range = [&](int i0, int &ea, int &eb) {
     ea = (i0 == 0) ? e0 : emid;
     eb = (i0 == 0 && NBLK > 1) ? emid : e0 + ne;
   };
-  auto prefetch_edges = [&](int i0) {
+  auto edges_prefetch = [&](int i0) {  // first kDensePre edges per thread of row block i0
     int ea, eb;
     edge_range(i0, ea, eb);
     const int tid = opaque_tid();
 #pragma unroll
-    for (int k = 0; k < PRE; ++k) {
+    for (int k = 0; k < kDensePre; ++k) {
       const unsigned e = (unsigned)min(tid + k * kDenseThreads, eb - ea - 1);  // clamped: plain loads
       pi[k] = ld32(g.rows + ea, e);
       pj[k] = ld32(g.col_ind + ea, e);
       pa[k] = ld32(attn_h + ea, e);
     }
   };
-  // Zero the tile, put the prefetched V image into LDS, scatter P of tile (i0, j0) into the tile (fp32).
-  auto load_tile = [&](int i0, int j0) {
+  // Zero the tile, scatter P of tile (i0, j0) into it (fp32), put the prefetched V image into LDS.
+  // `prefetched`: the first kDensePre edges per thread are already in (pi, pj, pa); the rest (or all of them) is
+  // fetched here, 8 per thread at a time.
+  auto load_tile = [&](int i0, int j0, bool prefetched) {
     int ea, eb;
     edge_range(i0, ea, eb);
     const int tid = opaque_tid();
     for (int k = tid; k < CR * TS / 4; k += kDenseThreads)
       reinterpret_cast<float4 *>(T)[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-    image_commit();
     __syncthreads();
+    if (prefetched) {
 #pragma unroll
-    for (int k = 0; k < PRE; ++k) {
-      const int j = pj[k] - n0 - j0;
-      if (tid + k * kDenseThreads < eb - ea && j >= 0 && j < CR) T[(pi[k] - n0 - i0) * TS + j] = pa[k];
+      for (int k = 0; k < kDensePre; ++k) {
+        const int j = pj[k] - n0 - j0;
+        if (tid + k * kDenseThreads < eb - ea && j >= 0 && j < CR) T[(pi[k] - n0 - i0) * TS + j] = pa[k];
+      }
     }
-    for (int e = ea + tid + PRE * kDenseThreads; e < eb; e += kDenseThreads) {
-      const int i = g.rows[e] - n0 - i0, j = g.col_ind[e] - n0 - j0;
-      if (j >= 0 && j < CR) T[i * TS + j] = attn_h[e];
+    constexpr int B = 8;
+    for (int base = prefetched ? kDensePre * kDenseThreads : 0; base < eb - ea; base += B * kDenseThreads) {
+      int bi[B], bj[B];
+      float ba[B];
+#pragma unroll
+      for (int k = 0; k < B; ++k) {
+        const unsigned e = (unsigned)min(base + tid + k * kDenseThreads, eb - ea - 1);
+        bi[k] = ld32(g.rows + ea, e);
+        bj[k] = ld32(g.col_ind + ea, e);
+        ba[k] = ld32(attn_h + ea, e);
+      }
+#pragma unroll
+      for (int k = 0; k < B; ++k) {
+        const int j = bj[k] - n0 - j0;
+        if (base + tid + k * kDenseThreads < eb - ea && j >= 0 && j < CR) T[(bi[k] - n0 - i0) * TS + j] = ba[k];
+      }
     }
+    image_commit();  // after the scatter: the edge loads were issued before the image's
     __syncthreads();
   };
   // this strip's 16 x 128 values -> its own rows of the tile, as interleaved bf16 hi | lo halves
@@ -370,7 +394,7 @@ __device__ __forceinline__ void dense_bwd_body(float *lds, const Csr &g, int n0,
     if (j < n) dense_store_acc<FT>(acc, 1.f, outb, (unsigned)j * (unsigned)hf + 4u * L.mq, accumulate);
   };
 
-  prefetch_edges(0);
+  edges_prefetch(0);
   image_prefetch(Vb, 0);
   for (int ic = 0; ic < NBLK; ++ic) {
     const int i0 = ic * CR, ni = min(n - i0, CR);
@@ -387,7 +411,7 @@ __device__ __forceinline__ void dense_bwd_body(float *lds, const Csr &g, int n0,
       }
 #pragma unroll
       for (int jc = 0; jc < NBLK; ++jc) {
-        load_tile(i0, jc * CR);  // image = V rows of column block jc, tile = P (fp32)
+        load_tile(i0, jc * CR, ic == 0 && jc == 0);  // image = V rows of column block jc, tile = P (fp32)
         DFGNN_DSTAMP(9)
         if (jc + 1 < NBLK) image_prefetch(Vb, (jc + 1) * CR);
         else image_prefetch(dOb, i0);  // next image: dO rows i0..
@@ -469,8 +493,7 @@ __device__ __forceinline__ void dense_bwd_body(float *lds, const Csr &g, int n0,
       image_commit();  // Q rows i0..
       if (jc + 1 < NBLK) {
         image_prefetch(Kb, (jc + 1) * CR);
-      } else if (ic + 1 < NBLK) {  // the next row block starts with its edges and V rows 0..
-        prefetch_edges(i0 + CR);
+      } else if (ic + 1 < NBLK) {  // the next row block starts with V rows 0..
         image_prefetch(Vb, 0);
       }
       __syncthreads();

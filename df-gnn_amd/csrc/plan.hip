@@ -304,7 +304,10 @@ int dfgnn_plan_build(int m, int nnz, int f, const int *row_ptr, const int *col_i
   int *unsorted = hi + m + (m + 1);
   plan_row_extent_kernel<<<(m + 255) / 256, 256, 0, s>>>(m, row_ptr, col_ind, lo, hi, unsorted);
   if (int rc = launch_status()) return rc;
-  plan_cut_kernel<<<1, kPlanThreads, 0, s>>>(m, nnz, f, kBlockLdsBudget, kBlockMergeNodes, row_ptr, plan);
+  // Widths with a matrix-core form: a merged range costs n^2 there and needs a second pass over 128-row blocks past
+  // 128 nodes, so small graphs are only merged up to 128 nodes.
+  const int merge_nodes = (f == 32 || f == 64 || f == 128) ? 128 : kBlockMergeNodes;
+  plan_cut_kernel<<<1, kPlanThreads, 0, s>>>(m, nnz, f, kBlockLdsBudget, merge_nodes, row_ptr, plan);
   if (int rc = launch_status()) return rc;
   if (hipError_t rc = hipMemcpyAsync(meta_host, plan, kPlanHeader * sizeof(int), hipMemcpyDeviceToHost, s)) return (int)rc;
   return (int)hipStreamSynchronize(s);
