@@ -32,7 +32,8 @@ typedef __attribute__((address_space(3))) bf16x4 *lds_bf16x4_ptr;
 
 constexpr int kDenseThreads = 512;                    // 8 waves: up to 256 VGPRs each, one workgroup per CU (LDS)
 constexpr int kDenseWaves = kDenseThreads / kWave;
-constexpr int kDenseChunkRows = 128;                  // rows of a feature matrix resident at a time
+constexpr int kDenseChunkRows = 128;                  // rows of a feature matrix resident at a time ...
+constexpr int kDenseWideRows = 160;                   // ... or 160, which lets ranges of 129-160 nodes do without a second chunk
 constexpr int kDenseMaxNodes = 255;                   // edge positions within a row fit a byte, 0xFF = no edge
 constexpr int kDensePre = 16;                         // edges per thread fetched ahead of the scatter loops
 
@@ -75,25 +76,26 @@ __device__ __forceinline__ LaneIds lane_ids() {
 }
 
 // ---- feature images -----------------------------------------------------------------------------------------------
-// 128 rows x F features: global -> registers (issued one phase ahead of its use) -> bf16 hi / lo images in LDS.
-template <int F>
+// ROWS rows x F features: global -> registers (issued one phase ahead of its use) -> bf16 hi / lo images in LDS.
+template <int F, int ROWS>
 struct DenseStageRegs {
-  static constexpr int PER = (kDenseChunkRows * (F / 8) + kDenseThreads - 1) / kDenseThreads;  // 8-float pieces per thread
+  static constexpr int PER = (ROWS * (F / 8) + kDenseThreads - 1) / kDenseThreads;  // 8-float pieces per thread
   float4 a[PER], b[PER];
 };
 
-// rows [row0, row0 + 128) of the matrix whose row 0 is `src` (global row stride hf floats); rows at or past n are zero
-template <int F>
-__device__ __forceinline__ void dense_stage_load(DenseStageRegs<F> &r, const float *__restrict__ src, size_t hf, int row0,
-                                                 int n) {
+// rows [row0, row0 + ROWS) of the matrix whose row 0 is `src` (global row stride hf floats); rows at or past row_end
+// are zero
+template <int F, int ROWS>
+__device__ __forceinline__ void dense_stage_load(DenseStageRegs<F, ROWS> &r, const float *__restrict__ src, size_t hf,
+                                                 int row0, int row_end) {
   constexpr int C8 = F / 8;
   const int tid = opaque_tid();
 #pragma unroll
-  for (int k = 0; k < DenseStageRegs<F>::PER; ++k) {
+  for (int k = 0; k < DenseStageRegs<F, ROWS>::PER; ++k) {
     const int idx = tid + k * kDenseThreads;
     const int row = idx / C8, c8 = idx - row * C8;
     r.a[k] = r.b[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (idx < kDenseChunkRows * C8 && row0 + row < n) {
+    if (idx < ROWS * C8 && row0 + row < row_end) {
       const unsigned off = (unsigned)(row0 + row) * (unsigned)hf + 8u * c8;  // < 2^31: a range has < 256 rows
       r.a[k] = ld32_f4(src, off);
       r.b[k] = ld32_f4(src, off + 4);
@@ -101,15 +103,15 @@ __device__ __forceinline__ void dense_stage_load(DenseStageRegs<F> &r, const flo
   }
 }
 
-template <int F>
-__device__ __forceinline__ void dense_stage_store(const DenseStageRegs<F> &r, __bf16 *hi, __bf16 *lo) {
+template <int F, int ROWS>
+__device__ __forceinline__ void dense_stage_store(const DenseStageRegs<F, ROWS> &r, __bf16 *hi, __bf16 *lo) {
   constexpr int C8 = F / 8, RS = DenseCfg<F>::RS;
   const int tid = opaque_tid();
 #pragma unroll
-  for (int k = 0; k < DenseStageRegs<F>::PER; ++k) {
+  for (int k = 0; k < DenseStageRegs<F, ROWS>::PER; ++k) {
     const int idx = tid + k * kDenseThreads;
     const int row = idx / C8, c8 = idx - row * C8;
-    if (idx < kDenseChunkRows * C8) {
+    if (idx < ROWS * C8) {
       bf16x8 h, l;
       split_bf16x8(r.a[k], r.b[k], h, l);
       *reinterpret_cast<bf16x8 *>(hi + row * RS + 8 * c8) = h;

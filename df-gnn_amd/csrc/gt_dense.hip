@@ -36,13 +36,15 @@ __device__ unsigned long long *dfgnn_dense_stamps = nullptr;  // [wg][16] phase 
 // =====================================================================================================================
 // forward
 // =====================================================================================================================
-template <int F, bool WRITE_ATTN, int NS>
+// NS strips per wave, chunks of CR rows of K / V, NCH chunks: (1, 128, 1) up to 128 nodes, (2, 160, 1) up to 160,
+// (2, 128, 2) up to 255.
+template <int F, bool WRITE_ATTN, int NS, int CR, int NCH>
 __device__ __forceinline__ void dense_fwd_body(float *lds, int lds_bytes, const Csr &g, int n0, int n, int e0, int ne,
                                                int head, const float *__restrict__ Q, const float *__restrict__ K,
                                                const float *__restrict__ V, float *__restrict__ attn_edge,
                                                float *__restrict__ out) {
   using D = DenseCfg<F>;
-  constexpr int RS = D::RS, KT = D::KT, FT = D::FT, NT = 8 * NS, CR = kDenseChunkRows;
+  constexpr int RS = D::RS, KT = D::KT, FT = D::FT, TPC = CR / 16, NT = TPC * NCH;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
   const int npad = (n + 31) & ~31, ntile = npad >> 4, nstrip = (n + 15) >> 4;
   const int MS = npad + 4;
@@ -69,8 +71,8 @@ __device__ __forceinline__ void dense_fwd_body(float *lds, int lds_bytes, const 
       pre_j[k] = ld32(g.col_ind + e0, e);
     }
   }
-  DenseStageRegs<F> st;
-  dense_stage_load<F>(st, Kb, hf, 0, n);
+  DenseStageRegs<F, CR> st;
+  dense_stage_load<F, CR>(st, Kb, hf, 0, n);
   bf16x8 qh[NS][KT], ql[NS][KT];
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
@@ -100,21 +102,21 @@ __device__ __forceinline__ void dense_fwd_body(float *lds, int lds_bytes, const 
       map[i * MS + j] = (unsigned char)(e - rp[i]);
     }
   }
-  dense_stage_store<F>(st, ihi, ilo);
+  dense_stage_store<F, CR>(st, ihi, ilo);
   __syncthreads();
   DFGNN_DSTAMP(1)
-  // the next image (K rows 128.. of a two-chunk range, else V rows 0..) lands during the S phase
-  if (NS == 1) dense_stage_load<F>(st, Vb, hf, 0, n);
-  else dense_stage_load<F>(st, Kb, hf, CR, n);
+  // the next image (the second K chunk of a two-chunk range, else V rows 0..) lands during the S phase
+  if (NCH == 1) dense_stage_load<F, CR>(st, Vb, hf, 0, n);
+  else dense_stage_load<F, CR>(st, Kb, hf, CR, n);
 
   // ---- S^T = K Q^T -------------------------------------------------------------------------------------------------------
   f32x4 S[NS][NT];
 #pragma unroll
-  for (int c = 0; c < NS; ++c) {
+  for (int c = 0; c < NCH; ++c) {
     if (c > 0) {
       __syncthreads();
-      dense_stage_store<F>(st, ihi, ilo);
-      dense_stage_load<F>(st, Vb, hf, 0, n);  // V rows 0.., for the first O^T chunk
+      dense_stage_store<F, CR>(st, ihi, ilo);
+      dense_stage_load<F, CR>(st, Vb, hf, 0, n);  // V rows 0.., for the first O^T chunk
       __syncthreads();
     }
     const LaneIds L = lane_ids();
@@ -122,8 +124,8 @@ __device__ __forceinline__ void dense_fwd_body(float *lds, int lds_bytes, const 
     for (int s = 0; s < NS; ++s) {
       if (wave + 8 * s < nstrip) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int jt = 8 * c + u;
+        for (int u = 0; u < TPC; ++u) {
+          const int jt = TPC * c + u;
           S[s][jt] = (jt < ntile) ? dense_rows_mma<F>(ihi, ilo, u, qh[s], ql[s], L) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
       }
@@ -205,10 +207,10 @@ __device__ __forceinline__ void dense_fwd_body(float *lds, int lds_bytes, const 
 #pragma unroll
     for (int ft = 0; ft < FT; ++ft) o[s][ft] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int c = 0; c < NS; ++c) {
+  for (int c = 0; c < NCH; ++c) {
     __syncthreads();  // every strip is done with the previous image
-    dense_stage_store<F>(st, ihi, ilo);
-    if (c + 1 < NS) dense_stage_load<F>(st, Vb, hf, (c + 1) * CR, n);
+    dense_stage_store<F, CR>(st, ihi, ilo);
+    if (c + 1 < NCH) dense_stage_load<F, CR>(st, Vb, hf, (c + 1) * CR, n);
     __syncthreads();
     if (c == 0) { DFGNN_DSTAMP(4) }
     const LaneIds L = lane_ids();
@@ -216,8 +218,8 @@ __device__ __forceinline__ void dense_fwd_body(float *lds, int lds_bytes, const 
     for (int s = 0; s < NS; ++s) {
       if (wave + 8 * s < nstrip) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int jb = 4 * c + u;  // 32-column block of P
+        for (int u = 0; u < CR / 32; ++u) {
+          const int jb = (CR / 32) * c + u;  // 32-column block of P
           if (2 * jb < ntile) dense_cols_mma<F>(o[s], ihi, ilo, u, S[s][2 * jb], S[s][2 * jb + 1], L);
         }
       }
@@ -244,9 +246,11 @@ __global__ __launch_bounds__(kDenseThreads) void gt_dense_fwd_kernel(Csr g, cons
   const int n0 = fit[2 * blockIdx.x], n1 = fit[2 * blockIdx.x + 1] & kPlanRangeMask;
   const int n = n1 - n0, e0 = g.row_ptr[n0], ne = g.row_ptr[n1] - e0;
   if (n <= kDenseChunkRows)
-    dense_fwd_body<F, WRITE_ATTN, 1>(lds, lds_bytes, g, n0, n, e0, ne, blockIdx.y, Q, K, V, attn_edge, out);
+    dense_fwd_body<F, WRITE_ATTN, 1, kDenseChunkRows, 1>(lds, lds_bytes, g, n0, n, e0, ne, blockIdx.y, Q, K, V, attn_edge, out);
+  else if (n <= kDenseWideRows)
+    dense_fwd_body<F, WRITE_ATTN, 2, kDenseWideRows, 1>(lds, lds_bytes, g, n0, n, e0, ne, blockIdx.y, Q, K, V, attn_edge, out);
   else
-    dense_fwd_body<F, WRITE_ATTN, 2>(lds, lds_bytes, g, n0, n, e0, ne, blockIdx.y, Q, K, V, attn_edge, out);
+    dense_fwd_body<F, WRITE_ATTN, 2, kDenseChunkRows, 2>(lds, lds_bytes, g, n0, n, e0, ne, blockIdx.y, Q, K, V, attn_edge, out);
 #ifdef DFGNN_STAMPS
   if (threadIdx.x == 0 && dfgnn_dense_stamps)
     dfgnn_dense_stamps[((size_t)blockIdx.x * gridDim.y + blockIdx.y) * 16 + 15] = ((unsigned long long)n << 32) | (unsigned)ne;
@@ -256,89 +260,90 @@ __global__ __launch_bounds__(kDenseThreads) void gt_dense_fwd_kernel(Csr g, cons
 // =====================================================================================================================
 // backward
 // =====================================================================================================================
-constexpr int kDenseTileStride = 136;  // floats per tile row == 2 x 136 bf16 (hi | lo)
+// NBLK column blocks of CW columns each; rows are processed in blocks of RB rows (dP / P / dS of every column block
+// of a row block stay in registers):
+//   (CW, NBLK) = (128, 1)  up to 128 nodes : one 128 x 128 tile
+//              = (160, 1)  up to 160 nodes : two row blocks of <= 80 rows against all (<= 160) columns
+//              = (128, 2)  up to 255 nodes : two row blocks of 128 rows x two column blocks
+template <int CW, int NBLK>
+struct DenseBwdGeom {
+  static constexpr int RB = (CW == kDenseWideRows) ? 80 : 128;  // rows per row block
+  static constexpr int RBP = (RB + 31) & ~31;                  // ... padded to the 32-deep k-blocks of the products
+  static constexpr int U = CW / 16;                            // 16-column tiles per column block
+  static constexpr int TS = CW + 8;                            // floats per tile row == 2 x TS bf16 (hi | lo)
+};
 
-template <int F, int NBLK>
+template <int F, int CW, int NBLK>
 __device__ __forceinline__ void dense_bwd_body(float *lds, const Csr &g, int n0, int n, int e0, int ne, int head,
                                                const float *__restrict__ Q, const float *__restrict__ K,
                                                const float *__restrict__ V, const float *__restrict__ attn_edge,
                                                const float *__restrict__ dO, float *__restrict__ dQ,
                                                float *__restrict__ dK, float *__restrict__ dV) {
   using D = DenseCfg<F>;
-  constexpr int RS = D::RS, KT = D::KT, FT = D::FT, CR = kDenseChunkRows, TS = kDenseTileStride;
-  constexpr int TB = 2 * TS;                   // bf16 elements per interleaved tile row: hi at +0, lo at +TS
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);  // = this wave's strip of a 128-row block
-  __bf16 *ihi = reinterpret_cast<__bf16 *>(lds), *ilo = ihi + (size_t)CR * RS;
-  float *T = reinterpret_cast<float *>(ilo + (size_t)CR * RS);
+  using G = DenseBwdGeom<CW, NBLK>;
+  constexpr int RS = D::RS, KT = D::KT, FT = D::FT, RB = G::RB, RBP = G::RBP, U = G::U, TS = G::TS;
+  constexpr int TB = 2 * TS;  // bf16 elements per interleaved tile row: hi at +0, lo at +TS
+  constexpr int PRE = (CW == kDenseChunkRows && NBLK == 1) ? kDensePre : kDensePre / 2;  // edges fetched ahead per thread
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);  // = this wave's strip of a row block
+  __bf16 *ihi = reinterpret_cast<__bf16 *>(lds), *ilo = ihi + (size_t)CW * RS;
+  float *T = reinterpret_cast<float *>(ilo + (size_t)CW * RS);
   __bf16 *Tb = reinterpret_cast<__bf16 *>(T);
   const size_t hf = (size_t)g.h * F, hoff = (size_t)head * F;
   const float *Qb = Q + (size_t)n0 * hf + hoff, *Kb = K + (size_t)n0 * hf + hoff, *Vb = V + (size_t)n0 * hf + hoff,
               *dOb = dO + (size_t)n0 * hf + hoff;
   float *dQb = dQ + (size_t)n0 * hf + hoff, *dKb = dK + (size_t)n0 * hf + hoff, *dVb = dV + (size_t)n0 * hf + hoff;
   const float *attn_h = attn_edge + (size_t)head * g.nnz;
-  const int emid = (NBLK > 1) ? g.row_ptr[n0 + CR] : 0;  // first edge of row block 1
 
   DFGNN_DSTAMP(0)
-  // The image that is needed next is fetched one phase ahead into registers (`st`) -- for a single-block range; with
+  // The image that is needed next is fetched one phase ahead into registers (`st`) -- for a single column block; with
   // two column blocks the registers hold dP / P / dS of both and the image is fetched where it is stored.
-  DenseStageRegs<F> st;
+  DenseStageRegs<F, CW> st;
   const float *next_src = nullptr;
-  int next_row0 = 0;
-  bool next_deferred = false;
-  auto image_prefetch = [&](const float *src, int row0) {
-    const bool defer = NBLK > 1;  // two column blocks: dP / P / dS of both fill the register file
-    next_deferred = defer;
-    if (defer) {
+  int next_row0 = 0, next_end = 0;
+  auto image_prefetch = [&](const float *src, int row0, int row_end) {
+    if (NBLK > 1) {
       next_src = src;
       next_row0 = row0;
+      next_end = row_end;
     } else {
-      dense_stage_load<F>(st, src, hf, row0, n);
+      dense_stage_load<F, CW>(st, src, hf, row0, row_end);
     }
   };
   auto image_commit = [&]() {
-    if (next_deferred) dense_stage_load<F>(st, next_src, hf, next_row0, n);
-    dense_stage_store<F>(st, ihi, ilo);
+    if (NBLK > 1) dense_stage_load<F, CW>(st, next_src, hf, next_row0, next_end);
+    dense_stage_store<F, CW>(st, ihi, ilo);
   };
   // Edges of a row block (CSR order, contiguous) are fetched several per thread at a time -- loads first, then the
   // scatter into the fp32 tile -- so that a batch costs one memory round trip; the first batch of a range is
   // fetched ahead of everything else.
-  int pi[kDensePre], pj[kDensePre];
-  float pa[kDensePre];
-  auto edge_range = [&](int i0, int &ea, int &eb) {
-    ea = (i0 == 0) ? e0 : emid;
-    eb = (i0 == 0 && NBLK > 1) ? emid : e0 + ne;
-  };
-  auto edges_prefetch = [&](int i0) {  // first kDensePre edges per thread of row block i0
-    int ea, eb;
-    edge_range(i0, ea, eb);
+  int pi[PRE], pj[PRE];
+  float pa[PRE];
+  auto edges_prefetch = [&](int ea, int eb) {  // first PRE edges per thread of the row block [ea, eb)
     const int tid = opaque_tid();
 #pragma unroll
-    for (int k = 0; k < kDensePre; ++k) {
+    for (int k = 0; k < PRE; ++k) {
       const unsigned e = (unsigned)min(tid + k * kDenseThreads, eb - ea - 1);  // clamped: plain loads
       pi[k] = ld32(g.rows + ea, e);
       pj[k] = ld32(g.col_ind + ea, e);
       pa[k] = ld32(attn_h + ea, e);
     }
   };
-  // Zero the tile, scatter P of tile (i0, j0) into it (fp32), put the prefetched V image into LDS.
-  // `prefetched`: the first kDensePre edges per thread are already in (pi, pj, pa); the rest (or all of them) is
-  // fetched here, 8 per thread at a time.
-  auto load_tile = [&](int i0, int j0, bool prefetched) {
-    int ea, eb;
-    edge_range(i0, ea, eb);
+  // Zero the tile, scatter P of tile (i0, j0) into it (fp32; edges [ea, eb) are the rows of the row block), put the
+  // prefetched V image into LDS.  `prefetched`: the first PRE edges per thread are already in (pi, pj, pa).
+  auto load_tile = [&](int i0, int j0, int ea, int eb, bool prefetched) {
     const int tid = opaque_tid();
-    for (int k = tid; k < CR * TS / 4; k += kDenseThreads)
+    for (int k = tid; k < RBP * TS / 4; k += kDenseThreads)
       reinterpret_cast<float4 *>(T)[k] = make_float4(0.f, 0.f, 0.f, 0.f);
     __syncthreads();
     if (prefetched) {
 #pragma unroll
-      for (int k = 0; k < kDensePre; ++k) {
+      for (int k = 0; k < PRE; ++k) {
         const int j = pj[k] - n0 - j0;
-        if (tid + k * kDenseThreads < eb - ea && j >= 0 && j < CR) T[(pi[k] - n0 - i0) * TS + j] = pa[k];
+        if (tid + k * kDenseThreads < eb - ea && j >= 0 && j < CW) T[(pi[k] - n0 - i0) * TS + j] = pa[k];
       }
     }
     constexpr int B = 8;
-    for (int base = prefetched ? kDensePre * kDenseThreads : 0; base < eb - ea; base += B * kDenseThreads) {
+    for (int base = prefetched ? PRE * kDenseThreads : 0; base < eb - ea; base += B * kDenseThreads) {
       int bi[B], bj[B];
       float ba[B];
 #pragma unroll
@@ -351,18 +356,18 @@ __device__ __forceinline__ void dense_bwd_body(float *lds, const Csr &g, int n0,
 #pragma unroll
       for (int k = 0; k < B; ++k) {
         const int j = bj[k] - n0 - j0;
-        if (base + tid + k * kDenseThreads < eb - ea && j >= 0 && j < CR) T[(bi[k] - n0 - i0) * TS + j] = ba[k];
+        if (base + tid + k * kDenseThreads < eb - ea && j >= 0 && j < CW) T[(bi[k] - n0 - i0) * TS + j] = ba[k];
       }
     }
     image_commit();  // after the scatter: the edge loads were issued before the image's
     __syncthreads();
   };
-  // this strip's 16 x 128 values -> its own rows of the tile, as interleaved bf16 hi | lo halves
-  auto strip_to_tile = [&](const f32x4 (&X)[8]) {
+  // this strip's 16 x CW values -> its own rows of the tile, as interleaved bf16 hi | lo halves
+  auto strip_to_tile = [&](const f32x4 (&X)[U]) {
     const LaneIds L = lane_ids();
     __bf16 *trow = Tb + (wave * 16 + L.mi) * TB + 4 * L.mq;
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < U; ++u) {
       bf16x4 h4, l4;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -374,18 +379,18 @@ __device__ __forceinline__ void dense_bwd_body(float *lds, const Csr &g, int n0,
       *reinterpret_cast<bf16x4 *>(trow + TS + 16 * u) = l4;
     }
   };
-  // out^T[f][c] = sum_i X[i][f] Y[i][c]: X = the image (ni rows), Y = the bf16 tile, c = this wave's 16 columns
-  // (rows j0 + 16 wave .. of the output)
-  auto column_phase = [&](float *outb, int j0, int ni, bool accumulate) {
+  // out^T[f][c] = sum_i X[i][f] Y[i][c]: X = the image (ni rows), Y = the bf16 tile, c = the 16 columns of column
+  // strip cs (rows j0 + 16 cs .. of the output)
+  auto column_strip = [&](float *outb, int j0, int cs, int ni, bool accumulate) {
     const LaneIds L = lane_ids();
-    const int j = j0 + wave * 16 + L.mi;
+    const int j = j0 + cs * 16 + L.mi;
     f32x4 acc[FT];
 #pragma unroll
     for (int ft = 0; ft < FT; ++ft) acc[ft] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int ib = 0; ib < 4; ++ib) {
+    for (int ib = 0; ib < RBP / 32; ++ib) {
       if (32 * ib < ni) {
-        const int yoff = (32 * ib + 4 * L.mq + L.tq) * TB + 16 * wave + 4 * L.tp;
+        const int yoff = (32 * ib + 4 * L.mq + L.tq) * TB + 16 * cs + 4 * L.tp;
         const bf16x8 yh = dense_tr_pair(Tb + yoff, 16 * TB);
         const bf16x8 yl = dense_tr_pair(Tb + yoff + TS, 16 * TB);
         dense_kblock_mma<F>(acc, ihi, ilo, (32 * ib + 4 * L.mq + L.tq) * RS + 4 * L.tp, 16 * RS, yh, yl);
@@ -393,35 +398,71 @@ __device__ __forceinline__ void dense_bwd_body(float *lds, const Csr &g, int n0,
     }
     if (j < n) dense_store_acc<FT>(acc, 1.f, outb, (unsigned)j * (unsigned)hf + 4u * L.mq, accumulate);
   };
+  // one 16 x 16 output tile (column strip cs, feature tile ft): the unit of work for the strips past the eighth,
+  // which are dealt out tile by tile so that all waves share them
+  auto column_tile = [&](float *outb, int j0, int cs, int ft, int ni, bool accumulate) {
+    const LaneIds L = lane_ids();
+    const int j = j0 + cs * 16 + L.mi;
+    f32x4 acc[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int ib = 0; ib < RBP / 32; ++ib) {
+      if (32 * ib < ni) {
+        const int yoff = (32 * ib + 4 * L.mq + L.tq) * TB + 16 * cs + 4 * L.tp;
+        const bf16x8 yh = dense_tr_pair(Tb + yoff, 16 * TB);
+        const bf16x8 yl = dense_tr_pair(Tb + yoff + TS, 16 * TB);
+        const int xoff = (32 * ib + 4 * L.mq + L.tq) * RS + 4 * L.tp + 16 * ft;
+        const bf16x8 xh = dense_tr_pair(ihi + xoff, 16 * RS);
+        const bf16x8 xl = dense_tr_pair(ilo + xoff, 16 * RS);
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, yh, acc[0], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xl, yh, acc[0], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, yl, acc[0], 0, 0, 0);
+      }
+    }
+    if (j < n) dense_store_acc<1>(acc, 1.f, outb, (unsigned)j * (unsigned)hf + 16u * ft + 4u * L.mq, accumulate);
+  };
+  auto column_phase = [&](float *outb, int j0, int ni, bool accumulate) {
+    const int nstrips = min(U, (n - j0 + 15) >> 4);
+    if (wave < nstrips) column_strip(outb, j0, wave, ni, accumulate);
+    if (U > kDenseWaves)
+      for (int unit = wave; unit < (nstrips - kDenseWaves) * FT; unit += kDenseWaves)
+        column_tile(outb, j0, kDenseWaves + unit / FT, unit % FT, ni, accumulate);
+  };
 
-  edges_prefetch(0);
-  image_prefetch(Vb, 0);
-  for (int ic = 0; ic < NBLK; ++ic) {
-    const int i0 = ic * CR, ni = min(n - i0, CR);
+  int ea = e0, eb = (RB < n) ? g.row_ptr[n0 + RB] : e0 + ne;  // edges of the current row block
+  edges_prefetch(ea, eb);
+  image_prefetch(Vb, 0, n);
+  for (int i0 = 0; i0 < n; i0 += RB) {
+    const int ni = min(n - i0, RB);
     const bool row_wave = wave * 16 < ni;
+    const bool first = i0 == 0;
 
     // ---- dP for every column block, t, dS ---------------------------------------------------------------------------
-    f32x4 dS[NBLK][8], Pr[NBLK][8];
+    f32x4 dS[NBLK][U], Pr[NBLK][U];
     {
       bf16x8 gh[KT], gl[KT];
       {
         const LaneIds L = lane_ids();
         const int i = i0 + wave * 16 + L.mi;
-        dense_row_operand<F>(gh, gl, dOb, hf, min(i, n - 1), i < n, L);
+        dense_row_operand<F>(gh, gl, dOb, hf, min(i, n - 1), i < i0 + ni, L);
       }
 #pragma unroll
       for (int jc = 0; jc < NBLK; ++jc) {
-        load_tile(i0, jc * CR, ic == 0 && jc == 0);  // image = V rows of column block jc, tile = P (fp32)
+        load_tile(i0, jc * CW, ea, eb, first && jc == 0);  // image = V rows of column block jc, tile = P (fp32)
         DFGNN_DSTAMP(9)
-        if (jc + 1 < NBLK) image_prefetch(Vb, (jc + 1) * CR);
-        else image_prefetch(dOb, i0);  // next image: dO rows i0..
+        if (jc + 1 < NBLK) image_prefetch(Vb, (jc + 1) * CW, n);
+        else image_prefetch(dOb, i0, i0 + ni);  // next image: dO rows of this row block
         if (row_wave) {
           const LaneIds L = lane_ids();
+          const int nj = n - jc * CW;
 #pragma unroll
-          for (int u = 0; u < 8; ++u) {
-            dS[jc][u] = dense_rows_mma<F>(ihi, ilo, u, gh, gl, L);  // dP for now
-            const float4 p = *reinterpret_cast<const float4 *>(T + (wave * 16 + L.mi) * TS + 16 * u + 4 * L.mq);
-            Pr[jc][u] = f32x4{p.x, p.y, p.z, p.w};
+          for (int u = 0; u < U; ++u) {
+            if (16 * u < nj) {
+              dS[jc][u] = dense_rows_mma<F>(ihi, ilo, u, gh, gl, L);  // dP for now
+              const float4 p = *reinterpret_cast<const float4 *>(T + (wave * 16 + L.mi) * TS + 16 * u + 4 * L.mq);
+              Pr[jc][u] = f32x4{p.x, p.y, p.z, p.w};
+            } else {
+              dS[jc][u] = Pr[jc][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
           }
         }
         if (jc + 1 < NBLK) __syncthreads();  // the next tile overwrites the image and the tile
@@ -433,14 +474,14 @@ __device__ __forceinline__ void dense_bwd_body(float *lds, const Csr &g, int n0,
 #pragma unroll
       for (int jc = 0; jc < NBLK; ++jc)
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
+        for (int u = 0; u < U; ++u)
 #pragma unroll
           for (int r = 0; r < 4; ++r) t = fmaf(Pr[jc][u][r], dS[jc][u][r], t);
       t = xor16_32_sum(t);  // a row lives on 4 lanes of this wave
 #pragma unroll
       for (int jc = 0; jc < NBLK; ++jc)
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
+        for (int u = 0; u < U; ++u)
 #pragma unroll
           for (int r = 0; r < 4; ++r) dS[jc][u][r] = Pr[jc][u][r] * (dS[jc][u][r] - t);
     }
@@ -449,16 +490,16 @@ __device__ __forceinline__ void dense_bwd_body(float *lds, const Csr &g, int n0,
     // ---- dV^T = dO^T P, column block by column block (last first: its fp32 tile has just been consumed) -----------------
 #pragma unroll
     for (int jj = 0; jj < NBLK; ++jj) {
-      const int jc = NBLK - 1 - jj, j0 = jc * CR;
+      const int jc = NBLK - 1 - jj, j0 = jc * CW;
       if (row_wave) strip_to_tile(Pr[jc]);  // own rows only
       if (jj == 0) {
         __syncthreads();  // every strip is done with the V image
         image_commit();
-        image_prefetch(Kb, 0);  // next image: K rows 0..
+        image_prefetch(Kb, 0, n);  // next image: K rows 0..
       }
       __syncthreads();
       DFGNN_DSTAMP(3)
-      if (wave * 16 < n - j0) column_phase(dVb, j0, ni, ic > 0);
+      column_phase(dVb, j0, ni, !first);
       __syncthreads();  // tile free (and, after the last block, the dO image)
     }
     DFGNN_DSTAMP(4)
@@ -469,17 +510,17 @@ __device__ __forceinline__ void dense_bwd_body(float *lds, const Csr &g, int n0,
     for (int ft = 0; ft < FT; ++ft) qacc[ft] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int jc = 0; jc < NBLK; ++jc) {
-      const int j0 = jc * CR, nj = min(n - j0, CR);
+      const int j0 = jc * CW, nj = min(n - j0, CW);
       if (row_wave) strip_to_tile(dS[jc]);
-      image_commit();             // K rows j0..
-      image_prefetch(Qb, i0);     // next image: Q rows i0..
+      image_commit();                       // K rows j0..
+      image_prefetch(Qb, i0, i0 + ni);      // next image: Q rows of this row block
       __syncthreads();
       DFGNN_DSTAMP(5)
       if (row_wave) {
         const LaneIds L = lane_ids();
         const __bf16 *srow = Tb + (wave * 16 + L.mi) * TB + 8 * L.mq;
 #pragma unroll
-        for (int jb = 0; jb < 4; ++jb) {
+        for (int jb = 0; jb < CW / 32; ++jb) {
           if (32 * jb < nj) {
             // natural k order: element t of lane (mi, mq) is column 32 jb + 8 mq + t of dS / that row of K
             const bf16x8 sh = *reinterpret_cast<const bf16x8 *>(srow + 32 * jb);
@@ -490,21 +531,24 @@ __device__ __forceinline__ void dense_bwd_body(float *lds, const Csr &g, int n0,
       }
       DFGNN_DSTAMP(6)
       __syncthreads();  // K image free
-      image_commit();  // Q rows i0..
+      image_commit();   // Q rows of this row block
       if (jc + 1 < NBLK) {
-        image_prefetch(Kb, (jc + 1) * CR);
-      } else if (ic + 1 < NBLK) {  // the next row block starts with V rows 0..
-        image_prefetch(Vb, 0);
+        image_prefetch(Kb, (jc + 1) * CW, n);
+      } else if (i0 + RB < n) {  // the next row block starts with its edges and V rows 0..
+        ea = eb;
+        eb = (i0 + 2 * RB < n) ? g.row_ptr[n0 + i0 + 2 * RB] : e0 + ne;
+        if (NBLK == 1) edges_prefetch(ea, eb);
+        image_prefetch(Vb, 0, n);
       }
       __syncthreads();
       DFGNN_DSTAMP(7)
-      if (wave * 16 < nj) column_phase(dKb, j0, ni, ic > 0);
+      column_phase(dKb, j0, ni, !first);
       __syncthreads();  // Q image and dS tile free
     }
     if (row_wave) {
       const LaneIds L = lane_ids();
       const int i = i0 + wave * 16 + L.mi;
-      if (i < n) dense_store_acc<FT>(qacc, 1.f, dQb, (unsigned)i * (unsigned)hf + 4u * L.mq, false);
+      if (i < i0 + ni) dense_store_acc<FT>(qacc, 1.f, dQb, (unsigned)i * (unsigned)hf + 4u * L.mq, false);
     }
     DFGNN_DSTAMP(8)
   }
@@ -518,8 +562,12 @@ __global__ __launch_bounds__(kDenseThreads) void gt_dense_bwd_kernel(
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int n0 = fit[2 * blockIdx.x], n1 = fit[2 * blockIdx.x + 1] & kPlanRangeMask;
   const int n = n1 - n0, e0 = g.row_ptr[n0], ne = g.row_ptr[n1] - e0;
-  if (n <= kDenseChunkRows) dense_bwd_body<F, 1>(lds, g, n0, n, e0, ne, blockIdx.y, Q, K, V, attn_edge, dO, dQ, dK, dV);
-  else dense_bwd_body<F, 2>(lds, g, n0, n, e0, ne, blockIdx.y, Q, K, V, attn_edge, dO, dQ, dK, dV);
+  if (n <= kDenseChunkRows)
+    dense_bwd_body<F, kDenseChunkRows, 1>(lds, g, n0, n, e0, ne, blockIdx.y, Q, K, V, attn_edge, dO, dQ, dK, dV);
+  else if (n <= kDenseWideRows)
+    dense_bwd_body<F, kDenseWideRows, 1>(lds, g, n0, n, e0, ne, blockIdx.y, Q, K, V, attn_edge, dO, dQ, dK, dV);
+  else
+    dense_bwd_body<F, kDenseChunkRows, 2>(lds, g, n0, n, e0, ne, blockIdx.y, Q, K, V, attn_edge, dO, dQ, dK, dV);
 #ifdef DFGNN_STAMPS
   if (threadIdx.x == 0 && dfgnn_dense_stamps)
     dfgnn_dense_stamps[((size_t)blockIdx.x * gridDim.y + blockIdx.y) * 16 + 15] = ((unsigned long long)n << 32) | (unsigned)ne;
