@@ -399,6 +399,62 @@ def test_block_kernels_match_oracle_and_general_path(oracle_mod, h, f, bs, unit_
     assert torch.allclose(out_b, out_n, atol=1e-5, rtol=1e-4)
 
 
+@pytest.mark.parametrize("h,f", [(1, 128), (2, 64), (3, 32)])
+def test_dense_kernels_every_geometry(oracle_mod, h, f):
+    """Matrix-core kernels (gt_dense.hip) vs the oracle on a batch whose ranges hit every code path: tiny graphs
+    (1 strip), <= 128 nodes (one tile), 129-160 nodes (160-row images, two row blocks), 161-255 nodes (2 x 2 tiles),
+    a graph with isolated nodes / empty rows, and one graph with a duplicate edge (must NOT be marked dense)."""
+    import fused_gtconv as gt
+    from DFGNN.layers import preprocess_Hyper_fw_bw
+    from DFGNN.utils import Graph, batch
+    rng = np.random.default_rng(17 + f)
+
+    def er(n, p, drop_rows=()):
+        iu, ju = np.triu_indices(n, k=1)
+        keep = rng.random(len(iu)) < p
+        keep &= ~np.isin(iu, drop_rows) & ~np.isin(ju, drop_rows)
+        return np.concatenate([iu[keep], ju[keep]]), np.concatenate([ju[keep], iu[keep]])
+
+    graphs = []
+    for n, p in ((9, 0.9), (17, 0.6), (64, 0.5), (128, 0.35), (129, 0.3), (145, 0.4), (160, 0.3), (161, 0.3), (200, 0.25),
+                 (255, 0.2)):
+        s_, d_ = er(n, p)
+        graphs.append(Graph(s_, d_, n))
+    s_, d_ = er(70, 0.5, drop_rows=(0, 33, 69))                     # isolated nodes: empty rows and columns
+    graphs.append(Graph(s_, d_, 70))
+    s_, d_ = er(40, 0.6)
+    graphs.append(Graph(np.concatenate([s_, s_[:1]]), np.concatenate([d_, d_[:1]]), 40))   # one duplicate edge
+    g = batch(graphs).to(DEV)
+    A, rows, row_ptr, col_ind, val, col_ptr, row_ind, val_idx, smem = preprocess_Hyper_fw_bw(g)
+    m = g.num_nodes()
+    from DFGNN.utils import synthetic as S
+    Q, K, V = S.gt_features(m, h, f, seed=5, device=DEV)
+    args = (row_ptr, col_ind, rows, val, col_ptr, row_ind, val_idx, smem, Q, K, V)
+    out, attn = gt.gt_hyper_forward(*args)
+    plan = row_ptr._dfgnn_plans[f]
+    raw = plan.buf.cpu().numpy()[12:12 + 2 * plan.num_fit].reshape(-1, 2)
+    n0s, n1s = raw[:, 0], raw[:, 1] & ~((1 << 30) | (1 << 29))
+    nn = n1s - n0s
+    dense = (raw[:, 1] & (1 << 29)) != 0
+    assert dense[:plan.num_dense].all() and not dense[plan.num_dense:].any()
+    dn = nn[dense]
+    assert (dn <= 128).any() and ((dn > 128) & (dn <= 160)).any() and (dn > 160).any() and dn.max() == 255
+    dup0 = m - 40                                                    # first node of the graph with the duplicate edge
+    hit = (n0s < m) & (n1s > dup0)
+    assert hit.any() and not dense[hit].any()                        # its range must stay on the edge-walking kernels
+    n_ = lambda t: t.cpu().numpy()  # noqa: E731
+    want, want_attn = oracle_mod.gt_forward(n_(row_ptr), n_(col_ind), n_(val), n_(Q), n_(K), n_(V), want_attn=True)
+    _close(out, want, "dense fwd")
+    _close(attn, want_attn, "dense attn_edge")
+    _close(gt.gt_hyper_inference(row_ptr, col_ind, rows, val, smem, Q, K, V)[0], want, "dense inference")
+    dO = torch.randn(m, h, f, generator=torch.Generator().manual_seed(3)).to(DEV)
+    wq, wk, wv = oracle_mod.gt_backward(n_(row_ptr), n_(col_ind), n_(val), n_(Q), n_(K), n_(V), n_(dO))
+    dQ, dK, dV = gt.gt_backward(*args, attn, dO)
+    _close(dQ, wq, "dense dQ")
+    _close(dK, wk, "dense dK")
+    _close(dV, wv, "dense dV")
+
+
 def test_block_plan_mixed_fit_and_spill(oracle_mod):
     """A batch holding one graph too large for LDS: its rows take the general kernel (spill chunks), the
     other graphs the resident kernel; isolated nodes form their own closed ranges."""
