@@ -249,8 +249,10 @@ __global__ __launch_bounds__(kPlanThreads) void plan_cut_kernel(int m, int nnz, 
     for (int i = t; i < N; i += kPlanThreads) {
       if (i < nfit) {
         const int n0 = fit[2 * i], n1 = fit[2 * i + 1] & kPlanRangeMask;
-        // key: dense ranges first, then by edge count (a dense range has < 2^16 edges)
-        s_end[i] = ((fit[2 * i + 1] & kPlanDense) ? (1 << 30) : 0) + min(row_ptr[n1] - row_ptr[n0], (1 << 30) - 1);
+        // key: dense ranges first, among them those of more than 128 nodes first (the matrix-core kernels run them
+        // in a loop of their own), then by edge count
+        const bool dn = (fit[2 * i + 1] & kPlanDense) != 0;
+        s_end[i] = (dn ? (1 << 30) : 0) + ((dn && n1 - n0 > 128) ? (1 << 29) : 0) + min(row_ptr[n1] - row_ptr[n0], (1 << 29) - 1);
       } else {
         s_end[i] = -1;
       }

@@ -314,8 +314,11 @@ def test_block_plan_structure():
     dense = (raw[:, 1] & (1 << 29)) != 0
     nd = plan.num_dense
     assert dense[:nd].all() and not dense[nd:].any()                                     # dense ranges come first,
-    assert (np.diff(edges_in_order[:nd]) <= 0).all() and (np.diff(edges_in_order[nd:]) <= 0).all()  # largest first
     nn = (fit[:, 1] - fit[:, 0]).astype(np.int64)
+    nbig = int((nn[:nd] > 128).sum())
+    assert (nn[:nbig] > 128).all()                                                       # those of > 128 nodes first,
+    for a, b in ((0, nbig), (nbig, nd), (nd, nfit)):                                     # each group largest first
+        assert (np.diff(edges_in_order[a:b]) <= 0).all()
     assert (dense == ((nn <= 255) & (32 * edges_in_order >= nn * nn))).all()             # no duplicate edges: all eligible
     assert nd > 0
     fit = fit[np.argsort(fit[:, 0])]
