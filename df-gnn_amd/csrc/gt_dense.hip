@@ -10,12 +10,14 @@
 //            The mask is a byte map [i][j] -> position of edge (i, j) in row i (0xFF: no edge), built once per
 //            range in LDS from the CSR arrays; it also tells where P_ij goes in attn_edge.
 // Backward:  P (attn_edge) is scattered into a dense fp32 tile; off-edge pairs have P = 0, hence dS = 0: no mask.
+//            dV^T = dO^T P first (dO image resident; the strips take their dO rows -- the register operand of the next
+//            product -- from it, so dO is read from global memory once), then
 //            dP^T = V dO^T ;  t_i = sum_j P_ij dP_ij ;  dS = P o (dP - t)        (registers)
-//            dV^T = dO^T P ,  dQ^T = K^T dS^T ,  dK^T = Q^T dS                   (P / dS through a bf16 tile in LDS)
+//            dQ^T = K^T dS^T ,  dK^T = Q^T dS                                    (P / dS through a bf16 tile in LDS)
 //            A row block of 128 rows keeps dP / P / dS of all (one or two) 128-column blocks in registers, so t_i
 //            needs no extra sweep and dQ accumulates in registers; dK / dV of a two-block range are accumulated
 //            across the row blocks by the lane that wrote them.
-// LDS: one feature image (K then V; V, dO, K, Q in turn; 72 KB) + the byte map (forward) or one 128 x 136-float
+// LDS: one feature image (K then V; dO, V, K, Q in turn; 72 KB) + the byte map (forward) or one 128 x 136-float
 // tile (backward: P as fp32, then P and dS as interleaved bf16 hi | lo rows, 68 KB).  The next image's global
 // loads are issued one phase ahead into registers, so a phase change costs a barrier and an LDS store.
 #include <type_traits>
@@ -328,9 +330,9 @@ __device__ __forceinline__ void dense_bwd_body(float *lds, const Csr &g, int n0,
       pa[k] = ld32(attn_h + ea, e);
     }
   };
-  // Zero the tile, scatter P of tile (i0, j0) into it (fp32; edges [ea, eb) are the rows of the row block), put the
-  // prefetched V image into LDS.  `prefetched`: the first PRE edges per thread are already in (pi, pj, pa).
-  auto load_tile = [&](int i0, int j0, int ea, int eb, bool prefetched) {
+  // Zero the tile, scatter P of tile (i0, j0) into it (fp32; edges [ea, eb) are the rows of the row block) and, if
+  // `commit`, put the prefetched image into LDS.  `prefetched`: the first PRE edges per thread are in (pi, pj, pa).
+  auto load_tile = [&](int i0, int j0, int ea, int eb, bool prefetched, bool commit) {
     const int tid = opaque_tid();
     for (int k = tid; k < RBP * TS / 4; k += kDenseThreads)
       reinterpret_cast<float4 *>(T)[k] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -359,7 +361,7 @@ __device__ __forceinline__ void dense_bwd_body(float *lds, const Csr &g, int n0,
         if (base + tid + k * kDenseThreads < eb - ea && j >= 0 && j < CW) T[(bi[k] - n0 - i0) * TS + j] = ba[k];
       }
     }
-    image_commit();  // after the scatter: the edge loads were issued before the image's
+    if (commit) image_commit();  // after the scatter: the edge loads were issued before the image's
     __syncthreads();
   };
   // this strip's 16 x CW values -> its own rows of the tile, as interleaved bf16 hi | lo halves
@@ -430,43 +432,66 @@ __device__ __forceinline__ void dense_bwd_body(float *lds, const Csr &g, int n0,
 
   int ea = e0, eb = (RB < n) ? g.row_ptr[n0 + RB] : e0 + ne;  // edges of the current row block
   edges_prefetch(ea, eb);
-  image_prefetch(Vb, 0, n);
+  image_prefetch(dOb, 0, min(n, RB));
   for (int i0 = 0; i0 < n; i0 += RB) {
     const int ni = min(n - i0, RB);
     const bool row_wave = wave * 16 < ni;
     const bool first = i0 == 0;
 
-    // ---- dP for every column block, t, dS ---------------------------------------------------------------------------
+    // ---- dV^T = dO^T P, column block by column block; the strips pick up their dO rows (the register operand of
+    //      dP) and their P values on the way: dO is read from global memory once ---------------------------------------
     f32x4 dS[NBLK][U], Pr[NBLK][U];
-    {
-      bf16x8 gh[KT], gl[KT];
-      {
+    bf16x8 gh[KT], gl[KT];
+#pragma unroll
+    for (int jc = 0; jc < NBLK; ++jc) {
+      const int j0 = jc * CW;
+      load_tile(i0, j0, ea, eb, first && jc == 0, jc == 0);  // tile = P (fp32); image = dO rows of this row block
+      DFGNN_DSTAMP(9)
+      if (jc + 1 == NBLK) image_prefetch(Vb, 0, n);  // next image: V rows 0..
+      if (row_wave) {
         const LaneIds L = lane_ids();
-        const int i = i0 + wave * 16 + L.mi;
-        dense_row_operand<F>(gh, gl, dOb, hf, min(i, n - 1), i < i0 + ni, L);
-      }
+        if (jc == 0) {
+          const int off = (wave * 16 + L.mi) * RS + 8 * L.mq;
 #pragma unroll
-      for (int jc = 0; jc < NBLK; ++jc) {
-        load_tile(i0, jc * CW, ea, eb, first && jc == 0);  // image = V rows of column block jc, tile = P (fp32)
-        DFGNN_DSTAMP(9)
-        if (jc + 1 < NBLK) image_prefetch(Vb, (jc + 1) * CW, n);
-        else image_prefetch(dOb, i0, i0 + ni);  // next image: dO rows of this row block
-        if (row_wave) {
-          const LaneIds L = lane_ids();
-          const int nj = n - jc * CW;
-#pragma unroll
-          for (int u = 0; u < U; ++u) {
-            if (16 * u < nj) {
-              dS[jc][u] = dense_rows_mma<F>(ihi, ilo, u, gh, gl, L);  // dP for now
-              const float4 p = *reinterpret_cast<const float4 *>(T + (wave * 16 + L.mi) * TS + 16 * u + 4 * L.mq);
-              Pr[jc][u] = f32x4{p.x, p.y, p.z, p.w};
-            } else {
-              dS[jc][u] = Pr[jc][u] = f32x4{0.f, 0.f, 0.f, 0.f};
-            }
+          for (int t = 0; t < KT; ++t) {
+            gh[t] = *reinterpret_cast<const bf16x8 *>(ihi + off + 32 * t);
+            gl[t] = *reinterpret_cast<const bf16x8 *>(ilo + off + 32 * t);
           }
         }
-        if (jc + 1 < NBLK) __syncthreads();  // the next tile overwrites the image and the tile
+        const int nj = n - j0;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          if (16 * u < nj) {
+            const float4 p = *reinterpret_cast<const float4 *>(T + (wave * 16 + L.mi) * TS + 16 * u + 4 * L.mq);
+            Pr[jc][u] = f32x4{p.x, p.y, p.z, p.w};
+          } else {
+            Pr[jc][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+          }
+        }
+        strip_to_tile(Pr[jc]);  // in place, own rows only
       }
+      __syncthreads();
+      DFGNN_DSTAMP(3)
+      column_phase(dVb, j0, ni, !first);
+      __syncthreads();  // tile free (and, after the last block, the dO image)
+    }
+    DFGNN_DSTAMP(4)
+
+    // ---- dP^T = V dO^T for every column block, t, dS ---------------------------------------------------------------
+#pragma unroll
+    for (int jc = 0; jc < NBLK; ++jc) {
+      image_commit();  // V rows of column block jc
+      if (jc + 1 < NBLK) image_prefetch(Vb, (jc + 1) * CW, n);
+      else image_prefetch(Kb, 0, n);  // next image: K rows 0..
+      __syncthreads();
+      if (row_wave) {
+        const LaneIds L = lane_ids();
+        const int nj = n - jc * CW;
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+          dS[jc][u] = (16 * u < nj) ? dense_rows_mma<F>(ihi, ilo, u, gh, gl, L) : f32x4{0.f, 0.f, 0.f, 0.f};  // dP for now
+      }
+      __syncthreads();  // the next image overwrites this one
     }
     DFGNN_DSTAMP(1)
     if (row_wave) {
@@ -486,23 +511,6 @@ __device__ __forceinline__ void dense_bwd_body(float *lds, const Csr &g, int n0,
           for (int r = 0; r < 4; ++r) dS[jc][u][r] = Pr[jc][u][r] * (dS[jc][u][r] - t);
     }
     DFGNN_DSTAMP(2)
-
-    // ---- dV^T = dO^T P, column block by column block (last first: its fp32 tile has just been consumed) -----------------
-#pragma unroll
-    for (int jj = 0; jj < NBLK; ++jj) {
-      const int jc = NBLK - 1 - jj, j0 = jc * CW;
-      if (row_wave) strip_to_tile(Pr[jc]);  // own rows only
-      if (jj == 0) {
-        __syncthreads();  // every strip is done with the V image
-        image_commit();
-        image_prefetch(Kb, 0, n);  // next image: K rows 0..
-      }
-      __syncthreads();
-      DFGNN_DSTAMP(3)
-      column_phase(dVb, j0, ni, !first);
-      __syncthreads();  // tile free (and, after the last block, the dO image)
-    }
-    DFGNN_DSTAMP(4)
 
     // ---- dQ^T = K^T dS^T (accumulated over the column blocks in registers) and dK^T = Q^T dS ---------------------------
     f32x4 qacc[FT];
@@ -534,11 +542,11 @@ __device__ __forceinline__ void dense_bwd_body(float *lds, const Csr &g, int n0,
       image_commit();   // Q rows of this row block
       if (jc + 1 < NBLK) {
         image_prefetch(Kb, (jc + 1) * CW, n);
-      } else if (i0 + RB < n) {  // the next row block starts with its edges and V rows 0..
+      } else if (i0 + RB < n) {  // the next row block starts with its edges and its dO rows
         ea = eb;
         eb = (i0 + 2 * RB < n) ? g.row_ptr[n0 + i0 + 2 * RB] : e0 + ne;
         if (NBLK == 1) edges_prefetch(ea, eb);
-        image_prefetch(Vb, 0, n);
+        image_prefetch(dOb, i0 + RB, min(n, i0 + 2 * RB));
       }
       __syncthreads();
       DFGNN_DSTAMP(7)
