@@ -93,6 +93,8 @@ int launch_gt_dense_fwd(const Csr &g, const Plan &p, const float *Q, const float
 int launch_gt_dense_bwd(const Csr &g, const Plan &p, const float *Q, const float *K, const float *V,
                         const float *attn_edge, const float *grad_out, float *dQ, float *dK, float *dV,
                         hipStream_t s);
+int launch_gat_dense_fwd(const Csr &g, const Plan &p, const float *attn_row, const float *attn_col, float slope,
+                         const float *X, float *out, hipStream_t s);
 int launch_gt_tiling_fwd(const Csr &g, const float *Q, const float *K, const float *V, float *out,
                          hipStream_t s);
 int launch_gt_sddmm(const Csr &g, const float *Q, const float *K, float *logits, hipStream_t s);

@@ -85,16 +85,24 @@ __global__ __launch_bounds__(kBlockThreads) void gat_block_fwd_kernel(Csr g, con
   }
 }
 
+bool dense_enabled();  // gt_block.hip
+
 int launch_gat_block_fwd(const Csr &g, const Plan &p, const float *attn_row, const float *attn_col, float slope,
                          const float *X, float *edge_ws, float *out, hipStream_t s) {
   if (p.num_fit == 0) return 0;
+  // dense ranges (first in the list) go to the matrix-core kernel (gt_dense.hip: masked dense attention, P X on MFMA)
+  const int first = (g.rows && dense_enabled()) ? p.num_dense : 0;
+  if (first > 0)
+    if (int rc = launch_gat_dense_fwd(g, p, attn_row, attn_col, slope, X, out, s)) return rc;
+  if (first == p.num_fit) return 0;
   if (p.num_edge_global > 0 && !edge_ws) return kErrBadArg;
-  const dim3 grid(p.num_fit, g.h);
+  const dim3 grid(p.num_fit - first, g.h);
+  const int *fit = p.fit() + 2 * (size_t)first;
   const size_t lds = block_lds_bytes(p, g.f);
   return dispatch_vec4(g.f, [&](auto cfg) {
     using C = decltype(cfg);
     if (int rc = set_max_lds(gat_block_fwd_kernel<C>)) return rc;
-    gat_block_fwd_kernel<C><<<grid, kBlockThreads, lds, s>>>(g, p.fit(), attn_row, attn_col, slope, X, edge_ws, out);
+    gat_block_fwd_kernel<C><<<grid, kBlockThreads, lds, s>>>(g, fit, attn_row, attn_col, slope, X, edge_ws, out);
     return launch_status();
   });
 }

@@ -40,11 +40,13 @@ __device__ unsigned long long *dfgnn_dense_stamps = nullptr;  // [wg][16] phase 
 // =====================================================================================================================
 // NS strips per wave, chunks of CR rows of K / V, NCH chunks: (1, 128, 1) up to 128 nodes, (2, 160, 1) up to 160,
 // (2, 128, 2) up to 255.
-template <int F, bool WRITE_ATTN, int NS, int CR, int NCH>
+// GAT = true: the logits are LeakyReLU(attn_row[i] + attn_col[j]) instead of <Q_i, K_j> (Q = attn_row [m, h],
+// K = attn_col [m, h], V = X): no K image and no first product, everything else is shared.
+template <int F, bool WRITE_ATTN, int NS, int CR, int NCH, bool GAT = false>
 __device__ __forceinline__ void dense_fwd_body(float *lds, int lds_bytes, const Csr &g, int n0, int n, int e0, int ne,
                                                int head, const float *__restrict__ Q, const float *__restrict__ K,
                                                const float *__restrict__ V, float *__restrict__ attn_edge,
-                                               float *__restrict__ out) {
+                                               float *__restrict__ out, float slope = 0.f) {
   using D = DenseCfg<F>;
   constexpr int RS = D::RS, KT = D::KT, FT = D::FT, TPC = CR / 16, NT = TPC * NCH;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
@@ -54,12 +56,15 @@ __device__ __forceinline__ void dense_fwd_body(float *lds, int lds_bytes, const 
   unsigned char *map = reinterpret_cast<unsigned char *>(ilo + (size_t)CR * RS);
   const int map_bytes = nstrip * 16 * MS;
   int *rp = reinterpret_cast<int *>(map + ((map_bytes + 15) & ~15));
-  float *pstage = reinterpret_cast<float *>(rp + ((n + 4) & ~3));  // [ne] normalised attention values, if it fits
+  float *acl = reinterpret_cast<float *>(rp + ((n + 4) & ~3));     // [npad] attn_col of the range (GAT only)
+  float *pstage = acl + (GAT ? npad : 0);                          // [ne] normalised attention values, if it fits
   const size_t fixed_bytes = (size_t)(reinterpret_cast<char *>(pstage) - reinterpret_cast<char *>(lds));
   const bool stage_attn = WRITE_ATTN && fixed_bytes + (size_t)ne * 4 <= (size_t)lds_bytes;
   const size_t hf = (size_t)g.h * F, hoff = (size_t)head * F;
   const float *Qb = Q + (size_t)n0 * hf + hoff, *Kb = K + (size_t)n0 * hf + hoff, *Vb = V + (size_t)n0 * hf + hoff;
   float *Ob = out + (size_t)n0 * hf + hoff;
+  (void)Qb;
+  (void)Kb;
 
   DFGNN_DSTAMP(0)
   // ---- every long-latency load of the prologue goes out before the first barrier --------------------------------------
@@ -74,18 +79,22 @@ __device__ __forceinline__ void dense_fwd_body(float *lds, int lds_bytes, const 
     }
   }
   DenseStageRegs<F, CR> st;
-  dense_stage_load<F, CR>(st, Kb, hf, 0, n);
+  dense_stage_load<F, CR>(st, GAT ? Vb : Kb, hf, 0, n);  // the first image: K rows (GAT: X rows)
   bf16x8 qh[NS][KT], ql[NS][KT];
+  float ar[NS];
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
     const LaneIds L = lane_ids();
     const int i = (wave + 8 * s) * 16 + L.mi;
-    dense_row_operand<F>(qh[s], ql[s], Qb, hf, min(i, n - 1), i < n, L);
+    if constexpr (GAT) ar[s] = Q[(size_t)(n0 + min(i, n - 1)) * g.h + head];
+    else dense_row_operand<F>(qh[s], ql[s], Qb, hf, min(i, n - 1), i < n, L);
   }
   {
     const int tid = opaque_tid();
     for (int k = tid; k < (map_bytes >> 2); k += kDenseThreads) reinterpret_cast<unsigned *>(map)[k] = 0xFFFFFFFFu;
     for (int k = tid; k <= n; k += kDenseThreads) rp[k] = g.row_ptr[n0 + k] - e0;
+    if constexpr (GAT)
+      for (int k = tid; k < npad; k += kDenseThreads) acl[k] = (k < n) ? K[(size_t)(n0 + k) * g.h + head] : 0.f;
   }
   __syncthreads();
   {  // byte map: position of every edge within its row (the plan guarantees distinct columns and rows < 255 long);
@@ -108,13 +117,28 @@ __device__ __forceinline__ void dense_fwd_body(float *lds, int lds_bytes, const 
   __syncthreads();
   DFGNN_DSTAMP(1)
   // the next image (the second K chunk of a two-chunk range, else V rows 0..) lands during the S phase
-  if (NCH == 1) dense_stage_load<F, CR>(st, Vb, hf, 0, n);
-  else dense_stage_load<F, CR>(st, Kb, hf, CR, n);
+  if constexpr (GAT) {
+    if (NCH > 1) dense_stage_load<F, CR>(st, Vb, hf, CR, n);
+  } else {
+    if (NCH == 1) dense_stage_load<F, CR>(st, Vb, hf, 0, n);
+    else dense_stage_load<F, CR>(st, Kb, hf, CR, n);
+  }
 
-  // ---- S^T = K Q^T -------------------------------------------------------------------------------------------------------
+  // ---- S^T = K Q^T (GAT: the rank-one logits) ------------------------------------------------------------------------
   f32x4 S[NS][NT];
+  if constexpr (GAT) {
+    const LaneIds L = lane_ids();
 #pragma unroll
-  for (int c = 0; c < NCH; ++c) {
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+      for (int jt = 0; jt < NT; ++jt) {
+        const float4 a = (jt < ntile) ? *reinterpret_cast<const float4 *>(acl + 16 * jt + 4 * L.mq) : make_float4(0.f, 0.f, 0.f, 0.f);
+        S[s][jt] = f32x4{leaky_relu(ar[s] + a.x, slope), leaky_relu(ar[s] + a.y, slope), leaky_relu(ar[s] + a.z, slope),
+                         leaky_relu(ar[s] + a.w, slope)};
+      }
+  }
+#pragma unroll
+  for (int c = 0; c < (GAT ? 0 : NCH); ++c) {
     if (c > 0) {
       __syncthreads();
       dense_stage_store<F, CR>(st, ihi, ilo);
@@ -210,10 +234,12 @@ __device__ __forceinline__ void dense_fwd_body(float *lds, int lds_bytes, const 
     for (int ft = 0; ft < FT; ++ft) o[s][ft] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int c = 0; c < NCH; ++c) {
-    __syncthreads();  // every strip is done with the previous image
-    dense_stage_store<F, CR>(st, ihi, ilo);
-    if (c + 1 < NCH) dense_stage_load<F, CR>(st, Vb, hf, (c + 1) * CR, n);
-    __syncthreads();
+    if (!(GAT && c == 0)) {  // (GAT: X rows 0.. are the image already)
+      __syncthreads();       // every strip is done with the previous image
+      dense_stage_store<F, CR>(st, ihi, ilo);
+      if (c + 1 < NCH) dense_stage_load<F, CR>(st, Vb, hf, (c + 1) * CR, n);
+      __syncthreads();
+    }
     if (c == 0) { DFGNN_DSTAMP(4) }
     const LaneIds L = lane_ids();
 #pragma unroll
@@ -257,6 +283,28 @@ __global__ __launch_bounds__(kDenseThreads) void gt_dense_fwd_kernel(Csr g, cons
   if (threadIdx.x == 0 && dfgnn_dense_stamps)
     dfgnn_dense_stamps[((size_t)blockIdx.x * gridDim.y + blockIdx.y) * 16 + 15] = ((unsigned long long)n << 32) | (unsigned)ne;
 #endif
+}
+
+// GAT 'hyper' forward over the dense ranges: replaces fused_gat_hyper_inference{,_vec4}
+// (DFGNN/src/fused_gatconv/fused_gatconv_hyper.cu:5-224) for them.
+template <int F>
+__global__ __launch_bounds__(kDenseThreads) void gat_dense_fwd_kernel(Csr g, const int *__restrict__ fit,
+                                                                      const float *__restrict__ attn_row,
+                                                                      const float *__restrict__ attn_col, float slope,
+                                                                      const float *__restrict__ X,
+                                                                      float *__restrict__ out, int lds_bytes) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int n0 = fit[2 * blockIdx.x], n1 = fit[2 * blockIdx.x + 1] & kPlanRangeMask;
+  const int n = n1 - n0, e0 = g.row_ptr[n0], ne = g.row_ptr[n1] - e0;
+  if (n <= kDenseChunkRows)
+    dense_fwd_body<F, false, 1, kDenseChunkRows, 1, true>(lds, lds_bytes, g, n0, n, e0, ne, blockIdx.y, attn_row, attn_col, X,
+                                                          nullptr, out, slope);
+  else if (n <= kDenseWideRows)
+    dense_fwd_body<F, false, 2, kDenseWideRows, 1, true>(lds, lds_bytes, g, n0, n, e0, ne, blockIdx.y, attn_row, attn_col, X,
+                                                         nullptr, out, slope);
+  else
+    dense_fwd_body<F, false, 2, kDenseChunkRows, 2, true>(lds, lds_bytes, g, n0, n, e0, ne, blockIdx.y, attn_row, attn_col, X,
+                                                          nullptr, out, slope);
 }
 
 // =====================================================================================================================
@@ -606,6 +654,18 @@ int launch_gt_dense_fwd(const Csr &g, const Plan &p, const float *Q, const float
       if (int rc = set_max_lds(gt_dense_fwd_kernel<F, false>)) return rc;
       gt_dense_fwd_kernel<F, false><<<grid, kDenseThreads, kLdsBytes, s>>>(g, p.fit(), Q, K, V, nullptr, out, kLdsBytes);
     }
+    return launch_status();
+  });
+}
+
+int launch_gat_dense_fwd(const Csr &g, const Plan &p, const float *attn_row, const float *attn_col, float slope,
+                         const float *X, float *out, hipStream_t s) {
+  if (p.num_dense == 0) return 0;
+  const dim3 grid(p.num_dense, g.h);
+  return dispatch_dense(g.f, [&](auto fc) {
+    constexpr int F = decltype(fc)::value;
+    if (int rc = set_max_lds(gat_dense_fwd_kernel<F>)) return rc;
+    gat_dense_fwd_kernel<F><<<grid, kDenseThreads, kLdsBytes, s>>>(g, p.fit(), attn_row, attn_col, slope, X, out, kLdsBytes);
     return launch_status();
   });
 }

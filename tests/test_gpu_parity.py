@@ -456,6 +456,11 @@ def test_dense_kernels_every_geometry(oracle_mod, h, f):
     _close(dQ, wq, "dense dQ")
     _close(dK, wk, "dense dK")
     _close(dV, wv, "dense dV")
+    # GAT 'hyper' over the same ranges (rank-one logits, P X on the matrix cores)
+    import fused_gatconv as gat
+    ar, ac, X = S.gat_features(m, h, f, seed=8, device=DEV)
+    want_gat = oracle_mod.gat_forward(n_(row_ptr), n_(col_ind), n_(ar), n_(ac), 0.2, n_(X))
+    _close(gat.gat_inference_hyper(smem, ar, ac, row_ptr, col_ind, rows, 0.2, X), want_gat, "dense GAT hyper")
 
 
 def test_block_plan_mixed_fit_and_spill(oracle_mod):

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Profiling helper: run one hot-path entry point a few times on the C3 workload (for rocprofv3).
-usage: python3 tools/run_kernel.py [fwd|bwd|fwd_infer] [iters] [batch_size]"""
+usage: python3 tools/run_kernel.py [fwd|bwd|fwd_infer|gat] [iters] [batch_size]"""
 import os
 import sys
 
@@ -22,6 +22,14 @@ A, rows, row_ptr, col_ind, val, col_ptr, row_ind, val_idx, smem = preprocess_Hyp
 m = g.num_nodes()
 Q, K, V = S.gt_features(m, 1, 128, seed=100, device=dev)
 dO = torch.randn_like(Q)
+if what == "gat":
+    import fused_gatconv as gat
+    ar, ac, X = S.gat_features(m, 1, 128, seed=6, device=dev)
+    for _ in range(iters):
+        gat.gat_inference_hyper(smem, ar, ac, row_ptr, col_ind, rows, 0.2, X)
+    torch.cuda.synchronize()
+    print("done gat", iters, m, g.num_edges())
+    sys.exit(0)
 for _ in range(iters):
     if what == "fwd_infer":
         gt.gt_hyper_inference(row_ptr, col_ind, rows, val, smem, Q, K, V)
