@@ -34,12 +34,10 @@ constexpr int kDenseThreads = 512;                    // 8 waves: up to 256 VGPR
 constexpr int kDenseWaves = kDenseThreads / kWave;
 constexpr int kDenseChunkRows = 128;                  // rows of a feature matrix resident at a time ...
 constexpr int kDenseWideRows = 160;                   // ... or 160, which lets ranges of 129-160 nodes do without a second chunk
-constexpr int kDenseMaxNodes = 255;                   // edge positions within a row fit a byte, 0xFF = no edge
 constexpr int kDensePre = 16;                         // edges per thread fetched ahead of the scatter loops
 
 template <int F>
 struct DenseCfg {
-  static constexpr bool ok = (F % 32 == 0) && (F <= 128);
   static constexpr int RS = F + 16;  // bf16 elements per image row
   static constexpr int KT = F / 32;  // MFMA k-steps across the feature dimension
   static constexpr int FT = F / 16;  // 16-feature tiles of the output

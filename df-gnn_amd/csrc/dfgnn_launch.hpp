@@ -87,7 +87,9 @@ int launch_gt_hyper_fwd(const Csr &g, const float *Q, const float *K, const floa
 bool block_width_ok(int f);
 int launch_gt_block_fwd(const Csr &g, const Plan &p, const float *Q, const float *K, const float *V,
                         float *attn_edge, float *edge_ws, float *out, hipStream_t s);
-// matrix-core kernels over the first p.num_dense fit ranges (unit edge values only)
+// matrix-core kernels over the first p.num_dense fit ranges (GT: unit edge values only); DFGNN_DENSE=0 in the
+// environment (diagnostic switch, read once) keeps every range on the edge-walking kernels
+bool dense_enabled();
 int launch_gt_dense_fwd(const Csr &g, const Plan &p, const float *Q, const float *K, const float *V,
                         float *attn_edge, float *out, hipStream_t s);
 int launch_gt_dense_bwd(const Csr &g, const Plan &p, const float *Q, const float *K, const float *V,

@@ -85,8 +85,6 @@ __global__ __launch_bounds__(kBlockThreads) void gat_block_fwd_kernel(Csr g, con
   }
 }
 
-bool dense_enabled();  // gt_block.hip
-
 int launch_gat_block_fwd(const Csr &g, const Plan &p, const float *attn_row, const float *attn_col, float slope,
                          const float *X, float *edge_ws, float *out, hipStream_t s) {
   if (p.num_fit == 0) return 0;

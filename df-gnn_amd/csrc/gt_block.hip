@@ -320,12 +320,6 @@ bool block_width_ok(int f) {
   }) == 1;
 }
 
-// DFGNN_DENSE=0 (diagnostic switch) keeps every range on the edge-walking kernels.
-bool dense_enabled() {
-  static const bool on = [] { const char *e = getenv("DFGNN_DENSE"); return !e || atoi(e) != 0; }();
-  return on;
-}
-
 int launch_gt_block_fwd(const Csr &g, const Plan &p, const float *Q, const float *K, const float *V,
                         float *attn_edge, float *edge_ws, float *out, hipStream_t s) {
   if (p.num_fit == 0) return 0;

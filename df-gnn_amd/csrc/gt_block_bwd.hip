@@ -245,8 +245,6 @@ __global__ __launch_bounds__(kBlockThreads) void gt_block_bwd_kernel(
   DFGNN_BSTAMP(11)
 }
 
-bool dense_enabled();  // gt_block.hip
-
 int launch_gt_block_bwd(const Csr &g, const Plan &p, const int *col_ptr, const int *row_ind, const int *val_idx,
                         const float *Q, const float *K, const float *V, const float *attn_edge,
                         const float *grad_out, float *edge_ws, float *dQ, float *dK, float *dV, hipStream_t s) {

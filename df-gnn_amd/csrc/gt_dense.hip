@@ -19,7 +19,10 @@
 //            across the row blocks by the lane that wrote them.
 // LDS: one feature image (K then V; dO, V, K, Q in turn; 72 KB) + the byte map (forward) or one 128 x 136-float
 // tile (backward: P as fp32, then P and dS as interleaved bf16 hi | lo rows, 68 KB).  The next image's global
-// loads are issued one phase ahead into registers, so a phase change costs a barrier and an LDS store.
+// loads are issued one phase ahead into registers, so a phase change costs a barrier and an LDS store.  Every barrier
+// is lds_barrier() (s_waitcnt lgkmcnt(0); s_barrier): __syncthreads() would also wait for vmcnt(0), i.e. for the
+// image that was just prefetched -- no thread ever reads another thread's global writes in these kernels.
+#include <cstdlib>
 #include <type_traits>
 
 #include "dfgnn_dense.hpp"
@@ -96,7 +99,7 @@ __device__ __forceinline__ void dense_fwd_body(float *lds, int lds_bytes, const 
     if constexpr (GAT)
       for (int k = tid; k < npad; k += kDenseThreads) acl[k] = (k < n) ? K[(size_t)(n0 + k) * g.h + head] : 0.f;
   }
-  __syncthreads();
+  lds_barrier();
   {  // byte map: position of every edge within its row (the plan guarantees distinct columns and rows < 255 long);
      // the edge loads were issued first, so this runs while the K rows are still on their way
     const int tid = opaque_tid();
@@ -114,7 +117,7 @@ __device__ __forceinline__ void dense_fwd_body(float *lds, int lds_bytes, const 
     }
   }
   dense_stage_store<F, CR>(st, ihi, ilo);
-  __syncthreads();
+  lds_barrier();
   DFGNN_DSTAMP(1)
   // the next image (the second K chunk of a two-chunk range, else V rows 0..) lands during the S phase
   if constexpr (GAT) {
@@ -140,10 +143,10 @@ __device__ __forceinline__ void dense_fwd_body(float *lds, int lds_bytes, const 
 #pragma unroll
   for (int c = 0; c < (GAT ? 0 : NCH); ++c) {
     if (c > 0) {
-      __syncthreads();
+      lds_barrier();
       dense_stage_store<F, CR>(st, ihi, ilo);
       dense_stage_load<F, CR>(st, Vb, hf, 0, n);  // V rows 0.., for the first O^T chunk
-      __syncthreads();
+      lds_barrier();
     }
     const LaneIds L = lane_ids();
 #pragma unroll
@@ -235,10 +238,10 @@ __device__ __forceinline__ void dense_fwd_body(float *lds, int lds_bytes, const 
 #pragma unroll
   for (int c = 0; c < NCH; ++c) {
     if (!(GAT && c == 0)) {  // (GAT: X rows 0.. are the image already)
-      __syncthreads();       // every strip is done with the previous image
+      lds_barrier();       // every strip is done with the previous image
       dense_stage_store<F, CR>(st, ihi, ilo);
       if (c + 1 < NCH) dense_stage_load<F, CR>(st, Vb, hf, (c + 1) * CR, n);
-      __syncthreads();
+      lds_barrier();
     }
     if (c == 0) { DFGNN_DSTAMP(4) }
     const LaneIds L = lane_ids();
@@ -384,7 +387,7 @@ __device__ __forceinline__ void dense_bwd_body(float *lds, const Csr &g, int n0,
     const int tid = opaque_tid();
     for (int k = tid; k < RBP * TS / 4; k += kDenseThreads)
       reinterpret_cast<float4 *>(T)[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-    __syncthreads();
+    lds_barrier();
     if (prefetched) {
 #pragma unroll
       for (int k = 0; k < PRE; ++k) {
@@ -410,7 +413,7 @@ __device__ __forceinline__ void dense_bwd_body(float *lds, const Csr &g, int n0,
       }
     }
     if (commit) image_commit();  // after the scatter: the edge loads were issued before the image's
-    __syncthreads();
+    lds_barrier();
   };
   // this strip's 16 x CW values -> its own rows of the tile, as interleaved bf16 hi | lo halves
   auto strip_to_tile = [&](const f32x4 (&X)[U]) {
@@ -518,10 +521,10 @@ __device__ __forceinline__ void dense_bwd_body(float *lds, const Csr &g, int n0,
         }
         strip_to_tile(Pr[jc]);  // in place, own rows only
       }
-      __syncthreads();
+      lds_barrier();
       DFGNN_DSTAMP(3)
       column_phase(dVb, j0, ni, !first);
-      __syncthreads();  // tile free (and, after the last block, the dO image)
+      lds_barrier();  // tile free (and, after the last block, the dO image)
     }
     DFGNN_DSTAMP(4)
 
@@ -531,7 +534,7 @@ __device__ __forceinline__ void dense_bwd_body(float *lds, const Csr &g, int n0,
       image_commit();  // V rows of column block jc
       if (jc + 1 < NBLK) image_prefetch(Vb, (jc + 1) * CW, n);
       else image_prefetch(Kb, 0, n);  // next image: K rows 0..
-      __syncthreads();
+      lds_barrier();
       if (row_wave) {
         const LaneIds L = lane_ids();
         const int nj = n - jc * CW;
@@ -539,7 +542,7 @@ __device__ __forceinline__ void dense_bwd_body(float *lds, const Csr &g, int n0,
         for (int u = 0; u < U; ++u)
           dS[jc][u] = (16 * u < nj) ? dense_rows_mma<F>(ihi, ilo, u, gh, gl, L) : f32x4{0.f, 0.f, 0.f, 0.f};  // dP for now
       }
-      __syncthreads();  // the next image overwrites this one
+      lds_barrier();  // the next image overwrites this one
     }
     DFGNN_DSTAMP(1)
     if (row_wave) {
@@ -570,7 +573,7 @@ __device__ __forceinline__ void dense_bwd_body(float *lds, const Csr &g, int n0,
       if (row_wave) strip_to_tile(dS[jc]);
       image_commit();                       // K rows j0..
       image_prefetch(Qb, i0, i0 + ni);      // next image: Q rows of this row block
-      __syncthreads();
+      lds_barrier();
       DFGNN_DSTAMP(5)
       if (row_wave) {
         const LaneIds L = lane_ids();
@@ -586,7 +589,7 @@ __device__ __forceinline__ void dense_bwd_body(float *lds, const Csr &g, int n0,
         }
       }
       DFGNN_DSTAMP(6)
-      __syncthreads();  // K image free
+      lds_barrier();  // K image free
       image_commit();   // Q rows of this row block
       if (jc + 1 < NBLK) {
         image_prefetch(Kb, (jc + 1) * CW, n);
@@ -596,10 +599,10 @@ __device__ __forceinline__ void dense_bwd_body(float *lds, const Csr &g, int n0,
         if (NBLK == 1) edges_prefetch(ea, eb);
         image_prefetch(dOb, i0 + RB, min(n, i0 + 2 * RB));
       }
-      __syncthreads();
+      lds_barrier();
       DFGNN_DSTAMP(7)
       column_phase(dKb, j0, ni, !first);
-      __syncthreads();  // Q image and dS tile free
+      lds_barrier();  // Q image and dS tile free
     }
     if (row_wave) {
       const LaneIds L = lane_ids();
@@ -633,6 +636,11 @@ __global__ __launch_bounds__(kDenseThreads) void gt_dense_bwd_kernel(
 // =====================================================================================================================
 // launchers: the first p.num_dense entries of the plan's fit list
 // =====================================================================================================================
+bool dense_enabled() {
+  static const bool on = [] { const char *e = getenv("DFGNN_DENSE"); return !e || atoi(e) != 0; }();
+  return on;
+}
+
 template <class Fn>
 static int dispatch_dense(int f, Fn &&fn) {
   if (f == 32) return fn(std::integral_constant<int, 32>{});

@@ -55,5 +55,31 @@ dO = torch.randn_like(out)
 for _ in range(2):
     gt.gt_backward(*args, attn, dO)
 print("BWD (stamps of the last row block)")
-run(lambda: gt.gt_backward(*args, attn, dO), ["tiles+dP", "t,dS", "P->tile,dO img", "dV", "dS->tile,K img", "dQ", "Q img", "dK"])
-# time from the start of the block to the end of the last load_tile (stamp 9)
+# stamp order in the kernel (last row block): 0 start, 9 tile loaded, 3 P tile ready, 4 dV done, 1 dP done, 2 dS done,
+# 5 dS tile + K image ready, 6 dQ done, 7 Q image ready, 8 dK done
+def run_bwd():
+    st = torch.zeros(nd * 16, dtype=torch.int64, device=dev)
+    assert L.dfgnn_debug_set_dense_stamps(st.data_ptr()) == 0
+    torch.cuda.synchronize()
+    e0.record(); gt.gt_backward(*args, attn, dO); e1.record(); torch.cuda.synchronize()
+    assert L.dfgnn_debug_set_dense_stamps(None) == 0
+    s = st.cpu().numpy().reshape(nd, 16)
+    n = s[:, 15] >> 32; ne = s[:, 15] & 0xffffffff
+    order = [0, 9, 3, 4, 1, 2, 5, 6, 7, 8]
+    names = ["tile+dO img", "P->tile", "dV", "V img,dP", "t,dS", "dS->tile,K img", "dQ", "Q img", "dK"]
+    t = s[:, order].astype(np.float64)
+    d = np.diff(t, axis=1)
+    print("  ms", e0.elapsed_time(e1))
+    for sel, lab in ((n <= 128, "n<=128"), (n > 128, "n>128 (phases of the LAST row block; the first column = everything before)")):
+        if sel.sum() == 0:
+            continue
+        tot = s[sel, 8].astype(np.float64) - s[sel, 0]
+        print(f"  {lab}: {sel.sum()} ranges, nodes mean {n[sel].mean():.0f}, edges mean {ne[sel].mean():.0f}; "
+              f"cycles per WG mean {tot.mean():.0f} p50 {np.median(tot):.0f} max {tot.max():.0f}")
+        print("    " + "  ".join(f"{nm} {np.median(d[sel, k]):.0f}" for k, nm in enumerate(names)))
+    tot = s[:, 8].astype(np.float64) - s[:, 0]
+    print("  sum of WG cycles / 256 CUs:", tot.sum() / 256)
+
+
+print("BWD")
+run_bwd()
