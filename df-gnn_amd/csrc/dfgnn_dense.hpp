@@ -124,11 +124,16 @@ template <int F>
 __device__ __forceinline__ void dense_row_operand(bf16x8 (&xh)[F / 32], bf16x8 (&xl)[F / 32], const float *__restrict__ base,
                                                   size_t hf, int row, bool valid, const LaneIds &L) {
   const unsigned off = (unsigned)row * (unsigned)hf + 8u * L.mq;
+  float4 a[F / 32], b[F / 32];
+#pragma unroll
+  for (int t = 0; t < F / 32; ++t) {  // all loads first: a conversion in between would wait for each piece in turn
+    a[t] = ld32_f4(base, off + 32 * t);
+    b[t] = ld32_f4(base, off + 32 * t + 4);
+  }
 #pragma unroll
   for (int t = 0; t < F / 32; ++t) {
-    float4 a = ld32_f4(base, off + 32 * t), b = ld32_f4(base, off + 32 * t + 4);
-    if (!valid) a = b = make_float4(0.f, 0.f, 0.f, 0.f);
-    split_bf16x8(a, b, xh[t], xl[t]);
+    if (!valid) a[t] = b[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+    split_bf16x8(a[t], b[t], xh[t], xl[t]);
   }
 }
 

@@ -70,7 +70,16 @@ __device__ __forceinline__ void dense_fwd_body(float *lds, int lds_bytes, const 
   (void)Kb;
 
   DFGNN_DSTAMP(0)
-  // ---- every long-latency load of the prologue goes out before the first barrier --------------------------------------
+  // ---- every long-latency load of the prologue goes out before the first barrier; the small ones that are needed
+  //      first go first (memory returns in order: behind the big loads they would wait for all of them) ---------------
+  int rp_mine = 0;       // row_ptr[n0 + tid] (n <= 255: one entry per thread covers the range)
+  float ac_mine = 0.f;   // GAT: attn_col[n0 + tid]
+  {
+    const int tid = opaque_tid();
+    if (tid <= n) rp_mine = g.row_ptr[n0 + tid];
+    if constexpr (GAT)
+      if (tid < n) ac_mine = K[(size_t)(n0 + tid) * g.h + head];
+  }
   int pre_i[kDensePre], pre_j[kDensePre];
   {
     const int tid = opaque_tid();
@@ -83,21 +92,29 @@ __device__ __forceinline__ void dense_fwd_body(float *lds, int lds_bytes, const 
   }
   DenseStageRegs<F, CR> st;
   dense_stage_load<F, CR>(st, GAT ? Vb : Kb, hf, 0, n);  // the first image: K rows (GAT: X rows)
-  bf16x8 qh[NS][KT], ql[NS][KT];
+  float4 qa[NS][KT], qb[NS][KT];  // this lane's pieces of its strips' Q rows, raw: converted after the map is built
   float ar[NS];
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
     const LaneIds L = lane_ids();
-    const int i = (wave + 8 * s) * 16 + L.mi;
-    if constexpr (GAT) ar[s] = Q[(size_t)(n0 + min(i, n - 1)) * g.h + head];
-    else dense_row_operand<F>(qh[s], ql[s], Qb, hf, min(i, n - 1), i < n, L);
+    const int i = min((wave + 8 * s) * 16 + L.mi, n - 1);
+    if constexpr (GAT) {
+      ar[s] = Q[(size_t)(n0 + i) * g.h + head];
+    } else {
+      const unsigned off = (unsigned)i * (unsigned)hf + 8u * L.mq;
+#pragma unroll
+      for (int t = 0; t < KT; ++t) {
+        qa[s][t] = ld32_f4(Qb, off + 32 * t);
+        qb[s][t] = ld32_f4(Qb, off + 32 * t + 4);
+      }
+    }
   }
   {
     const int tid = opaque_tid();
     for (int k = tid; k < (map_bytes >> 2); k += kDenseThreads) reinterpret_cast<unsigned *>(map)[k] = 0xFFFFFFFFu;
-    for (int k = tid; k <= n; k += kDenseThreads) rp[k] = g.row_ptr[n0 + k] - e0;
+    if (tid <= n) rp[tid] = rp_mine - e0;
     if constexpr (GAT)
-      for (int k = tid; k < npad; k += kDenseThreads) acl[k] = (k < n) ? K[(size_t)(n0 + k) * g.h + head] : 0.f;
+      if (tid < npad) acl[tid] = ac_mine;
   }
   lds_barrier();
   {  // byte map: position of every edge within its row (the plan guarantees distinct columns and rows < 255 long);
@@ -117,6 +134,20 @@ __device__ __forceinline__ void dense_fwd_body(float *lds, int lds_bytes, const 
     }
   }
   dense_stage_store<F, CR>(st, ihi, ilo);
+  bf16x8 qh[NS][KT], ql[NS][KT];
+  if constexpr (!GAT) {
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const LaneIds L = lane_ids();
+      const bool valid = (wave + 8 * s) * 16 + L.mi < n;
+#pragma unroll
+      for (int t = 0; t < KT; ++t) {
+        float4 a = qa[s][t], b = qb[s][t];
+        if (!valid) a = b = make_float4(0.f, 0.f, 0.f, 0.f);
+        split_bf16x8(a, b, qh[s][t], ql[s][t]);
+      }
+    }
+  }
   lds_barrier();
   DFGNN_DSTAMP(1)
   // the next image (the second K chunk of a two-chunk range, else V rows 0..) lands during the S phase
@@ -336,7 +367,7 @@ __device__ __forceinline__ void dense_bwd_body(float *lds, const Csr &g, int n0,
   using G = DenseBwdGeom<CW, NBLK>;
   constexpr int RS = D::RS, KT = D::KT, FT = D::FT, RB = G::RB, RBP = G::RBP, U = G::U, TS = G::TS;
   constexpr int TB = 2 * TS;  // bf16 elements per interleaved tile row: hi at +0, lo at +TS
-  constexpr int PRE = (CW == kDenseChunkRows && NBLK == 1) ? kDensePre : kDensePre / 2;  // edges fetched ahead per thread
+  constexpr int PRE = kDensePre;  // edges fetched ahead per thread
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);  // = this wave's strip of a row block
   __bf16 *ihi = reinterpret_cast<__bf16 *>(lds), *ilo = ihi + (size_t)CW * RS;
   float *T = reinterpret_cast<float *>(ilo + (size_t)CW * RS);
@@ -520,6 +551,13 @@ __device__ __forceinline__ void dense_bwd_body(float *lds, const Csr &g, int n0,
           }
         }
         strip_to_tile(Pr[jc]);  // in place, own rows only
+      } else {  // (defined on every path: otherwise the arrays are carried around the row-block loop in registers)
+#pragma unroll
+        for (int u = 0; u < U; ++u) Pr[jc][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (jc == 0) {
+#pragma unroll
+          for (int t = 0; t < KT; ++t) gh[t] = gl[t] = bf16x8{};
+        }
       }
       lds_barrier();
       DFGNN_DSTAMP(3)
@@ -541,6 +579,9 @@ __device__ __forceinline__ void dense_bwd_body(float *lds, const Csr &g, int n0,
 #pragma unroll
         for (int u = 0; u < U; ++u)
           dS[jc][u] = (16 * u < nj) ? dense_rows_mma<F>(ihi, ilo, u, gh, gl, L) : f32x4{0.f, 0.f, 0.f, 0.f};  // dP for now
+      } else {
+#pragma unroll
+        for (int u = 0; u < U; ++u) dS[jc][u] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
       lds_barrier();  // the next image overwrites this one
     }
