@@ -79,30 +79,35 @@ template <int F, int ROWS>
 struct DenseStageRegs {
   static constexpr int PER = (ROWS * (F / 8) + kDenseThreads - 1) / kDenseThreads;  // 8-float pieces per thread
   float4 a[PER], b[PER];
+  int row0, row_end;  // the image holds rows [row0, row0 + ROWS) of the matrix; rows at or past row_end are zero
 };
 
 // rows [row0, row0 + ROWS) of the matrix whose row 0 is `src` (global row stride hf floats); rows at or past row_end
-// are zero
+// (> row0) read as zero.  The loads are unconditional (addresses clamped to the last valid row, the zeroing happens
+// when the image is stored): a load under a branch is waited for right behind the branch, one round trip per piece.
 template <int F, int ROWS>
 __device__ __forceinline__ void dense_stage_load(DenseStageRegs<F, ROWS> &r, const float *__restrict__ src, size_t hf,
                                                  int row0, int row_end) {
   constexpr int C8 = F / 8;
   const int tid = opaque_tid();
+  r.row0 = row0;
+  r.row_end = row_end;
 #pragma unroll
   for (int k = 0; k < DenseStageRegs<F, ROWS>::PER; ++k) {
     const int idx = tid + k * kDenseThreads;
-    const int row = idx / C8, c8 = idx - row * C8;
-    r.a[k] = r.b[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (idx < ROWS * C8 && row0 + row < row_end) {
-      const unsigned off = (unsigned)(row0 + row) * (unsigned)hf + 8u * c8;  // < 2^31: a range has < 256 rows
-      r.a[k] = ld32_f4(src, off);
-      r.b[k] = ld32_f4(src, off + 4);
-    }
+    const int row = min(idx / C8, ROWS - 1), c8 = idx % C8;
+    const unsigned off = (unsigned)min(row0 + row, row_end - 1) * (unsigned)hf + 8u * c8;  // < 2^31: < 256 rows
+    r.a[k] = ld32_f4(src, off);
+    r.b[k] = ld32_f4(src, off + 4);
   }
 }
 
+// The trailing memory clobber keeps the loads of the next prefetch (usually into these same registers) from being
+// interleaved with the stores piece by piece: memory returns in order, so each piece would then wait for the loads
+// that were just issued.  (Pinning the bf16 conversion here with an empty asm, so that the scheduler cannot hoist it
+// and the wait for the data to the previous barrier, measured 2 % slower.)
 template <int F, int ROWS>
-__device__ __forceinline__ void dense_stage_store(const DenseStageRegs<F, ROWS> &r, __bf16 *hi, __bf16 *lo) {
+__device__ __forceinline__ void dense_stage_store(DenseStageRegs<F, ROWS> &r, __bf16 *hi, __bf16 *lo) {
   constexpr int C8 = F / 8, RS = DenseCfg<F>::RS;
   const int tid = opaque_tid();
 #pragma unroll
@@ -110,12 +115,15 @@ __device__ __forceinline__ void dense_stage_store(const DenseStageRegs<F, ROWS> 
     const int idx = tid + k * kDenseThreads;
     const int row = idx / C8, c8 = idx - row * C8;
     if (idx < ROWS * C8) {
+      const bool valid = r.row0 + row < r.row_end;
+      const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
       bf16x8 h, l;
-      split_bf16x8(r.a[k], r.b[k], h, l);
+      split_bf16x8(valid ? r.a[k] : z, valid ? r.b[k] : z, h, l);
       *reinterpret_cast<bf16x8 *>(hi + row * RS + 8 * c8) = h;
       *reinterpret_cast<bf16x8 *>(lo + row * RS + 8 * c8) = l;
     }
   }
+  asm volatile("" ::: "memory");
 }
 
 // 16 rows of a matrix as the register operand of D^T = Image . X^T: lane (mi, mq) holds X[row][32 t + 8 mq ..] for

@@ -9,6 +9,9 @@ for p in (ROOT, os.path.join(ROOT, "df-gnn_amd")):
     sys.path.insert(0, p)
 import torch  # noqa: E402
 
+import dfgnn_native  # noqa: E402
+if os.environ.get("DFGNN_LIB"):  # A/B runs of two builds
+    dfgnn_native.LIB_PATH = os.path.join(ROOT, "df-gnn_amd", os.environ["DFGNN_LIB"])
 import fused_gtconv as gt  # noqa: E402
 from DFGNN.layers import preprocess_Hyper_fw_bw  # noqa: E402
 from DFGNN.utils import synthetic as S  # noqa: E402
