@@ -147,20 +147,49 @@ __device__ __forceinline__ void dense_row_operand(bf16x8 (&xh)[F / 32], bf16x8 (
 
 // D^T tile u (image rows 16 u .. 16 u + 15) against a register row operand: 3 * F/32 MFMAs
 template <int F>
-__device__ __forceinline__ f32x4 dense_rows_mma(const __bf16 *ihi, const __bf16 *ilo, int u, const bf16x8 (&xh)[F / 32],
-                                                const bf16x8 (&xl)[F / 32], const LaneIds &L) {
+__device__ __forceinline__ void dense_rows_frag(bf16x8 (&ah)[F / 32], bf16x8 (&al)[F / 32], const __bf16 *ihi,
+                                                const __bf16 *ilo, int u, const LaneIds &L) {
   constexpr int RS = DenseCfg<F>::RS;
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   const int off = (16 * u + L.mi) * RS + 8 * L.mq;
 #pragma unroll
   for (int t = 0; t < F / 32; ++t) {
-    const bf16x8 ah = *reinterpret_cast<const bf16x8 *>(ihi + off + 32 * t);
-    const bf16x8 al = *reinterpret_cast<const bf16x8 *>(ilo + off + 32 * t);
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, xh[t], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, xl[t], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, xh[t], acc, 0, 0, 0);
+    ah[t] = *reinterpret_cast<const bf16x8 *>(ihi + off + 32 * t);
+    al[t] = *reinterpret_cast<const bf16x8 *>(ilo + off + 32 * t);
+  }
+}
+template <int F>
+__device__ __forceinline__ f32x4 dense_rows_mma_frag(const bf16x8 (&ah)[F / 32], const bf16x8 (&al)[F / 32],
+                                                     const bf16x8 (&xh)[F / 32], const bf16x8 (&xl)[F / 32]) {
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < F / 32; ++t) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[t], xh[t], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[t], xl[t], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[t], xh[t], acc, 0, 0, 0);
   }
   return acc;
+}
+template <int F>
+__device__ __forceinline__ f32x4 dense_rows_mma(const __bf16 *ihi, const __bf16 *ilo, int u, const bf16x8 (&xh)[F / 32],
+                                                const bf16x8 (&xl)[F / 32], const LaneIds &L) {
+  bf16x8 ah[F / 32], al[F / 32];
+  dense_rows_frag<F>(ah, al, ihi, ilo, u, L);
+  return dense_rows_mma_frag<F>(ah, al, xh, xl);
+}
+
+// D^T tiles 0 .. NTILES-1 of the resident image (those with 16 u < limit; the others are zero) against a register
+// row operand, the image fragments of tile u + 1 being fetched while tile u is multiplied
+template <int F, int NTILES>
+__device__ __forceinline__ void dense_rows_mma_strip(f32x4 (&out)[NTILES], const __bf16 *ihi, const __bf16 *ilo, int limit,
+                                                     const bf16x8 (&xh)[F / 32], const bf16x8 (&xl)[F / 32],
+                                                     const LaneIds &L) {
+  bf16x8 ah[2][F / 32], al[2][F / 32];
+  dense_rows_frag<F>(ah[0], al[0], ihi, ilo, 0, L);
+#pragma unroll
+  for (int u = 0; u < NTILES; ++u) {
+    if (u + 1 < NTILES) dense_rows_frag<F>(ah[(u + 1) & 1], al[(u + 1) & 1], ihi, ilo, u + 1, L);
+    out[u] = (16 * u < limit) ? dense_rows_mma_frag<F>(ah[u & 1], al[u & 1], xh, xl) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
 }
 
 // Two transposed 4-row reads -> one 8-element operand fragment (rows r .. r+3 and r + second .. of a column).
@@ -183,13 +212,13 @@ __device__ __forceinline__ void dense_split8(const f32x4 &x0, const f32x4 &x1, b
 
 // acc[ft] += X^T Y for one 32-deep k-block: X^T fragments come from the image through transposed reads (`xoff` =
 // this lane's element offset of feature tile 0, `second` = element offset between its two 4-row reads), Y is given
-// as operand fragments.  The X fragments of four feature tiles are fetched together and the products are issued as
-// three sweeps over four independent accumulators, so neither the LDS latency nor the MFMA result latency
+// as operand fragments.  The X fragments of GMAX (four or eight) feature tiles are fetched together and the products
+// are issued as three sweeps over that many independent accumulators, so neither the LDS latency nor the MFMA result latency
 // serialises the chain.
-template <int F>
+template <int F, int GMAX = 4>
 __device__ __forceinline__ void dense_kblock_mma(f32x4 (&acc)[F / 16], const __bf16 *ihi, const __bf16 *ilo, int xoff,
                                                  int second, const bf16x8 &yh, const bf16x8 &yl) {
-  constexpr int FT = F / 16, G = FT < 4 ? FT : 4;
+  constexpr int FT = F / 16, G = FT < GMAX ? FT : GMAX;
 #pragma unroll
   for (int f0 = 0; f0 < FT; f0 += G) {
     bf16x8 xh[G], xl[G];
@@ -209,13 +238,13 @@ __device__ __forceinline__ void dense_kblock_mma(f32x4 (&acc)[F / 16], const __b
 
 // acc[ft] += Image^T (features 16 ft .., image rows 32 jb ..) . Y, Y given as the accumulator pair (y0, y1) of a
 // D^T strip (permuted k order, see the header): the "P V" product of the forward
-template <int F>
+template <int F, int GMAX = 4>
 __device__ __forceinline__ void dense_cols_mma(f32x4 (&acc)[F / 16], const __bf16 *ihi, const __bf16 *ilo, int jb,
                                                const f32x4 &y0, const f32x4 &y1, const LaneIds &L) {
   constexpr int RS = DenseCfg<F>::RS;
   bf16x8 yh, yl;
   dense_split8(y0, y1, yh, yl);
-  dense_kblock_mma<F>(acc, ihi, ilo, (32 * jb + 4 * L.mq + L.tq) * RS + 4 * L.tp, 16 * RS, yh, yl);
+  dense_kblock_mma<F, GMAX>(acc, ihi, ilo, (32 * jb + 4 * L.mq + L.tq) * RS + 4 * L.tp, 16 * RS, yh, yl);
 }
 
 // accumulator tiles -> a global row: lane (mi, mq), register r of tile ft = feature 16 ft + 4 mq + r

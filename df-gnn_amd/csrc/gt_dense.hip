@@ -183,10 +183,14 @@ __device__ __forceinline__ void dense_fwd_body(float *lds, int lds_bytes, const 
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
       if (wave + 8 * s < nstrip) {
+        if constexpr (NS == 1 && NCH == 1) {
+          dense_rows_mma_strip<F, TPC>(S[s], ihi, ilo, 16 * ntile, qh[s], ql[s], L);  // (double-buffered fragments)
+        } else {
 #pragma unroll
-        for (int u = 0; u < TPC; ++u) {
-          const int jt = TPC * c + u;
-          S[s][jt] = (jt < ntile) ? dense_rows_mma<F>(ihi, ilo, u, qh[s], ql[s], L) : f32x4{0.f, 0.f, 0.f, 0.f};
+          for (int u = 0; u < TPC; ++u) {
+            const int jt = TPC * c + u;
+            S[s][jt] = (jt < ntile) ? dense_rows_mma<F>(ihi, ilo, u, qh[s], ql[s], L) : f32x4{0.f, 0.f, 0.f, 0.f};
+          }
         }
       }
     }
@@ -282,7 +286,7 @@ __device__ __forceinline__ void dense_fwd_body(float *lds, int lds_bytes, const 
 #pragma unroll
         for (int u = 0; u < CR / 32; ++u) {
           const int jb = (CR / 32) * c + u;  // 32-column block of P
-          if (2 * jb < ntile) dense_cols_mma<F>(o[s], ihi, ilo, u, S[s][2 * jb], S[s][2 * jb + 1], L);
+          if (2 * jb < ntile) dense_cols_mma<F, (NS == 1 ? 8 : 4)>(o[s], ihi, ilo, u, S[s][2 * jb], S[s][2 * jb + 1], L);
         }
       }
     }
@@ -477,7 +481,7 @@ __device__ __forceinline__ void dense_bwd_body(float *lds, const Csr &g, int n0,
         const int yoff = (32 * ib + 4 * L.mq + L.tq) * TB + 16 * cs + 4 * L.tp;
         const bf16x8 yh = dense_tr_pair(Tb + yoff, 16 * TB);
         const bf16x8 yl = dense_tr_pair(Tb + yoff + TS, 16 * TB);
-        dense_kblock_mma<F>(acc, ihi, ilo, (32 * ib + 4 * L.mq + L.tq) * RS + 4 * L.tp, 16 * RS, yh, yl);
+        dense_kblock_mma<F, (NBLK == 1 ? 8 : 4)>(acc, ihi, ilo, (32 * ib + 4 * L.mq + L.tq) * RS + 4 * L.tp, 16 * RS, yh, yl);
       }
     }
     if (j < n) dense_store_acc<FT>(acc, 1.f, outb, (unsigned)j * (unsigned)hf + 4u * L.mq, accumulate);
@@ -576,9 +580,13 @@ __device__ __forceinline__ void dense_bwd_body(float *lds, const Csr &g, int n0,
       if (row_wave) {
         const LaneIds L = lane_ids();
         const int nj = n - jc * CW;
+        if constexpr (NBLK == 1) {
+          dense_rows_mma_strip<F, U>(dS[jc], ihi, ilo, nj, gh, gl, L);  // dP for now (double-buffered fragments)
+        } else {
 #pragma unroll
-        for (int u = 0; u < U; ++u)
-          dS[jc][u] = (16 * u < nj) ? dense_rows_mma<F>(ihi, ilo, u, gh, gl, L) : f32x4{0.f, 0.f, 0.f, 0.f};  // dP for now
+          for (int u = 0; u < U; ++u)
+            dS[jc][u] = (16 * u < nj) ? dense_rows_mma<F>(ihi, ilo, u, gh, gl, L) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
       } else {
 #pragma unroll
         for (int u = 0; u < U; ++u) dS[jc][u] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -625,7 +633,7 @@ __device__ __forceinline__ void dense_bwd_body(float *lds, const Csr &g, int n0,
             // natural k order: element t of lane (mi, mq) is column 32 jb + 8 mq + t of dS / that row of K
             const bf16x8 sh = *reinterpret_cast<const bf16x8 *>(srow + 32 * jb);
             const bf16x8 sl = *reinterpret_cast<const bf16x8 *>(srow + TS + 32 * jb);
-            dense_kblock_mma<F>(qacc, ihi, ilo, (32 * jb + 8 * L.mq + L.tq) * RS + 4 * L.tp, 4 * RS, sh, sl);
+            dense_kblock_mma<F, (NBLK == 1 ? 8 : 4)>(qacc, ihi, ilo, (32 * jb + 8 * L.mq + L.tq) * RS + 4 * L.tp, 4 * RS, sh, sl);
           }
         }
       }
