@@ -21,6 +21,8 @@
 //
 // "Dense" (gt_dense.hip, dfgnn_dense.hpp): at most 255 nodes, at least one edge per 32 node pairs, f in {32, 64, 128}
 // and no duplicate edge in any row of the range -- the one thing a dense mask cannot represent.
+#include <type_traits>
+
 #include "../../include/dfgnn.h"
 #include "dfgnn_launch.hpp"
 
@@ -62,33 +64,58 @@ __global__ void plan_row_extent_kernel(int m, const int *__restrict__ row_ptr, c
   unsorted[i] = bad;  // 1: the row has a duplicate edge (or is too wide / long to be part of a dense range)
 }
 
-// Exclusive scan of part[0 .. kPlanThreads) in place by wave 0 (lane l owns 16 consecutive entries, a wave-level
-// shuffle scan combines the lane totals).  FORWARD: part[k] <- op(identity, part[0..k)); else the mirror image
-// (part[k] <- op over part(k..end)).  Every thread of the workgroup must call it (it contains the barriers).
-template <bool FORWARD, class Op>
-__device__ __forceinline__ void plan_scan_partials(int *part, int identity, Op op) {
-  constexpr int PER = kPlanThreads / kWave;
-  __syncthreads();
-  if (threadIdx.x < kWave) {
-    const int lane = threadIdx.x;
-    int v[PER];
+// In-place scan over m elements by the whole workgroup with coalesced accesses: wave w owns a contiguous span
+// (a multiple of 64 long), its lanes step through it 64 elements at a time (FORWARD: ascending; else descending, i.e.
+// a suffix scan); a wave-level shuffle scan plus a running carry gives every element its inclusive and exclusive
+// value: store(i, inclusive, exclusive).  load(i) may compute the element (fused flag evaluation).
+// Every thread must call it; it ends with a __syncthreads() (global writes of the pass are visible to the next).
+template <bool FORWARD, class Op, class Load, class Store>
+__device__ __forceinline__ void plan_block_scan(int m, int identity, int *wave_tot, Op op, Load load, Store store) {
+  constexpr int kWaves = kPlanThreads / kWave;
+  const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x / kWave;
+  const int span = ((m + kWaves * kWave - 1) / (kWaves * kWave)) * kWave;
+  const int r0 = min(m, w * span), r1 = min(m, r0 + span);
+  auto index = [&](int k) { return FORWARD ? r0 + k : r1 - 1 - k; };  // k-th element of this wave's span, scan order
+  constexpr int UNR = 8;  // elements per lane in flight: the loop is bound by the latency of its loads
+  int tot = identity;
+  for (int base = 0; base < r1 - r0; base += UNR * kWave) {
+    int x[UNR];
 #pragma unroll
-    for (int k = 0; k < PER; ++k) v[k] = part[FORWARD ? lane * PER + k : kPlanThreads - 1 - (lane * PER + k)];
-    int tot = identity;
-#pragma unroll
-    for (int k = 0; k < PER; ++k) tot = op(tot, v[k]);
-    int incl = tot;  // inclusive scan of the lane totals
-#pragma unroll
-    for (int o = 1; o < kWave; o <<= 1) {
-      const int up = __shfl_up(incl, o, kWave);
-      if (lane >= o) incl = op(incl, up);
+    for (int u = 0; u < UNR; ++u) {
+      const int k = base + u * kWave + lane;
+      x[u] = (k < r1 - r0) ? load(index(k)) : identity;
     }
-    int run = __shfl_up(incl, 1, kWave);
-    if (lane == 0) run = identity;
 #pragma unroll
-    for (int k = 0; k < PER; ++k) {
-      part[FORWARD ? lane * PER + k : kPlanThreads - 1 - (lane * PER + k)] = run;
-      run = op(run, v[k]);
+    for (int u = 0; u < UNR; ++u) tot = op(tot, x[u]);
+  }
+#pragma unroll
+  for (int o = kWave / 2; o > 0; o >>= 1) tot = op(tot, __shfl_xor(tot, o, kWave));
+  if (lane == 0) wave_tot[w] = tot;
+  __syncthreads();
+  int carry = identity;
+  for (int k = 0; k < kWaves; ++k)
+    if (FORWARD ? k < w : k > w) carry = op(carry, wave_tot[k]);
+  for (int base = 0; base < r1 - r0; base += UNR * kWave) {
+    int x[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const int k = base + u * kWave + lane;
+      x[u] = (k < r1 - r0) ? load(index(k)) : identity;
+    }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const int k = base + u * kWave + lane;
+      int v = x[u];
+#pragma unroll
+      for (int o = 1; o < kWave; o <<= 1) {
+        const int up = __shfl_up(v, o, kWave);
+        if (lane >= o) v = op(v, up);
+      }
+      const int incl = op(carry, v);
+      int excl = __shfl_up(incl, 1, kWave);
+      if (lane == 0) excl = carry;
+      if (k < r1 - r0) store(index(k), incl, excl);
+      carry = __shfl(incl, kWave - 1, kWave);
     }
   }
   __syncthreads();
@@ -100,7 +127,6 @@ __device__ __forceinline__ void plan_scan_partials(int *part, int identity, Op o
 __global__ __launch_bounds__(kPlanThreads) void plan_cut_kernel(int m, int nnz, int f, int budget_bytes,
                                                                 int merge_nodes,
                                                                 const int *__restrict__ row_ptr, int *plan) {
-  __shared__ int part[kPlanThreads];
   int *hdr = plan;
   int *fit = plan + kPlanHeader;
   int *spill = fit + 2 * (size_t)m;
@@ -109,56 +135,30 @@ __global__ __launch_bounds__(kPlanThreads) void plan_cut_kernel(int m, int nnz, 
   int *bounds = hi + m;  // [m + 1] ends of the natural closed ranges
   int *unsorted = bounds + m + 1;  // [m + 1] in: per-row 'has a duplicate edge' flag, out: exclusive prefix count
   const int t = threadIdx.x;
-  const int chunk = (m + kPlanThreads - 1) / kPlanThreads;
-  const int b = min(m, t * chunk), e = min(m, b + chunk);
+  __shared__ int wave_tot[kPlanThreads / kWave];
 
-  // prefix max of hi
-  int acc = -1;
-  for (int i = b; i < e; ++i) acc = max(acc, hi[i]);
-  part[t] = acc;
-  plan_scan_partials<true>(part, -1, [](int a, int b) { return max(a, b); });
-  acc = part[t];
-  for (int i = b; i < e; ++i) { acc = max(acc, hi[i]); hi[i] = acc; }
-  __syncthreads();
-  // suffix min of lo
-  acc = m;
-  for (int i = e - 1; i >= b; --i) acc = min(acc, lo[i]);
-  part[t] = acc;
-  plan_scan_partials<false>(part, m, [](int a, int b) { return min(a, b); });
-  acc = part[t];
-  for (int i = e - 1; i >= b; --i) { acc = min(acc, lo[i]); lo[i] = acc; }
-  __syncthreads();
-  // exclusive prefix count of the rows with duplicate edges (unsorted[m] = total)
-  {
-    int c = 0;
-    for (int i = b; i < e; ++i) c += unsorted[i];
-    part[t] = c;
-    plan_scan_partials<true>(part, 0, [](int a, int b) { return a + b; });
-    int run = part[t];
-    for (int i = b; i < e; ++i) {
-      const int v = unsorted[i];
-      unsorted[i] = run;
-      run += v;
-    }
-    if (e == m) unsorted[m] = run;  // every thread whose chunk ends at m holds the total
-    __syncthreads();
-  }
-  // count boundaries per thread chunk, scan, write
-  int cnt = 0;
-  for (int i = b; i < e; ++i) cnt += (hi[i] <= i && (i + 1 == m || lo[i + 1] >= i + 1)) ? 1 : 0;
-  part[t] = cnt;
-  plan_scan_partials<true>(part, 0, [](int a, int b) { return a + b; });
-  if (t == kPlanThreads - 1) hdr[7] = part[t] + cnt;  // number of natural ranges (temporary)
-  __syncthreads();
-  int pos = part[t];
-  for (int i = b; i < e; ++i)
-    if (hi[i] <= i && (i + 1 == m || lo[i + 1] >= i + 1)) bounds[pos++] = i + 1;
-  __syncthreads();
+  // (1) prefix max of hi, suffix min of lo, exclusive prefix count of the rows with duplicate edges
+  plan_block_scan<true>(m, -1, wave_tot, [](int a, int b) { return max(a, b); }, [&](int i) { return hi[i]; },
+                        [&](int i, int incl, int) { hi[i] = incl; });
+  plan_block_scan<false>(m, m, wave_tot, [](int a, int b) { return min(a, b); }, [&](int i) { return lo[i]; },
+                         [&](int i, int incl, int) { lo[i] = incl; });
+  plan_block_scan<true>(m, 0, wave_tot, [](int a, int b) { return a + b; }, [&](int i) { return unsorted[i]; },
+                        [&](int i, int incl, int excl) {
+                          unsorted[i] = excl;
+                          if (i == m - 1) unsorted[m] = incl;
+                        });
+  // (2) a boundary after row i iff pmax[i] <= i and smin[i+1] >= i+1: number them, write the ends of the natural ranges
+  plan_block_scan<true>(m, 0, wave_tot, [](int a, int b) { return a + b; },
+                        [&](int i) { return (hi[i] <= i && (i + 1 == m || lo[i + 1] >= i + 1)) ? 1 : 0; },
+                        [&](int i, int incl, int excl) {
+                          if (incl != excl) bounds[excl] = i + 1;
+                          if (i == m - 1) hdr[7] = incl;  // number of natural ranges (temporary)
+                        });
 
   // Greedy merge by thread 0.  The ends of the natural ranges and their row_ptr values are first copied to
   // LDS (when there are few enough) so the serial walk does not pay a global-memory round trip per range.
   constexpr int kCache = 4096;
-  __shared__ int s_end[kCache], s_rp[kCache];
+  __shared__ int s_end[kCache], s_rp[kCache], s_bad[kCache];
   __shared__ int s_nfit;
   const int nb = hdr[7];
   const bool cached = nb <= kCache;
@@ -167,6 +167,7 @@ __global__ __launch_bounds__(kPlanThreads) void plan_cut_kernel(int m, int nnz, 
       const int en = bounds[k];
       s_end[k] = en;
       s_rp[k] = row_ptr[en];
+      s_bad[k] = unsorted[en];  // rows with duplicate edges before the end of natural range k
     }
   __syncthreads();
   if (t == 0) {
@@ -174,13 +175,19 @@ __global__ __launch_bounds__(kPlanThreads) void plan_cut_kernel(int m, int nnz, 
     const bool dense_f = (f == 32 || f == 64 || f == 128);
     // LDS bytes of a range [n0, n1) holding ed edges: resident rows + 1/sum + rebased row_ptr + narrowed
     // column ids, plus (full only) the per-edge fp32 array.  Layout: dfgnn_block.hpp:carve_block_lds.
-    auto lite = [&](long n, long ed) -> long { return n * (long)f * 4 + n * 8 + ed * (n <= 256 ? 1 : 2); };
-    auto full = [&](long n, long ed) -> long { return lite(n, ed) + 4 * ed; };
-    auto flush = [&](int n0, int n1, int ed) {
+    // (32-bit arithmetic on clamped sizes -- this serial walk is latency-bound, and anything clamped is far over the
+    // budget anyway)
+    auto lite = [&](int n, int ed) -> int {
+      n = min(n, 1 << 16);
+      ed = min(ed, 1 << 24);
+      return n * (4 * f + 8) + ed * (n <= 256 ? 1 : 2);
+    };
+    auto full = [&](int n, int ed) -> int { return lite(n, ed) + 4 * min(ed, 1 << 24); };
+    auto flush = [&](int n0, int n1, int ed, int bad0, int bad1) {
       if (n1 <= n0) return;
       const bool edge_global = full(n1 - n0, ed) > budget_bytes;  // only ever true for an unmerged range
-      const long nn = n1 - n0;
-      const bool dense = dense_f && nn <= 255 && (long)ed * 32 >= nn * nn && unsorted[n1] == unsorted[n0];
+      const int nn = n1 - n0;
+      const bool dense = dense_f && nn <= 255 && min(ed, 1 << 24) * 32 >= nn * nn && bad1 == bad0;
       fit[2 * nfit] = n0;
       fit[2 * nfit + 1] = n1 | (edge_global ? kPlanEdgeGlobal : 0) | (dense ? kPlanDense : 0);
       nglobal += edge_global ? 1 : 0;
@@ -191,12 +198,25 @@ __global__ __launch_bounds__(kPlanThreads) void plan_cut_kernel(int m, int nnz, 
     };
     int cur0 = 0, cur1 = 0, prev = 0;          // current merged range [cur0, cur1), previous range end
     int rp_cur0 = row_ptr[0], rp_cur1 = rp_cur0, rp_prev = rp_cur0;
+    int bad_cur0 = 0, bad_cur1 = 0, bad_prev = 0;  // duplicate-edge row counts before cur0 / cur1 / prev
+    // (two instances of the walk: with a `cached ? lds : global` select per value the compiler issues the dependent
+    // global loads unconditionally -- 900 cycles per range instead of 60)
+    auto walk = [&](auto cached_c) {
+    constexpr bool kCached = decltype(cached_c)::value;
     for (int k = 0; k < nb; ++k) {
-      const int end = cached ? s_end[k] : bounds[k];
-      const int rp_end = cached ? s_rp[k] : row_ptr[end];
-      const long n_one = end - prev, e_one = rp_end - rp_prev;
+      int end, rp_end, bad_end;
+      if constexpr (kCached) {
+        end = s_end[k];
+        rp_end = s_rp[k];
+        bad_end = s_bad[k];
+      } else {
+        end = bounds[k];
+        rp_end = row_ptr[end];
+        bad_end = unsorted[end];
+      }
+      const int n_one = end - prev, e_one = rp_end - rp_prev;
       if (lite(n_one, e_one) > budget_bytes) {            // not even the feature rows of this range fit
-        flush(cur0, cur1, rp_cur1 - rp_cur0);
+        flush(cur0, cur1, rp_cur1 - rp_cur0, bad_cur0, bad_cur1);
         for (int r = prev; r < end; r += kHyperRows) {
           spill[2 * nspill] = r;
           spill[2 * nspill + 1] = min(end, r + kHyperRows);
@@ -204,26 +224,35 @@ __global__ __launch_bounds__(kPlanThreads) void plan_cut_kernel(int m, int nnz, 
         }
         cur0 = cur1 = end;
         rp_cur0 = rp_cur1 = rp_end;
+        bad_cur0 = bad_cur1 = bad_end;
       } else if (full(n_one, e_one) > budget_bytes) {     // rows fit, the per-edge array goes to global scratch
-        flush(cur0, cur1, rp_cur1 - rp_cur0);
-        flush(prev, end, (int)e_one);
+        flush(cur0, cur1, rp_cur1 - rp_cur0, bad_cur0, bad_cur1);
+        flush(prev, end, e_one, bad_prev, bad_end);
         cur0 = cur1 = end;
         rp_cur0 = rp_cur1 = rp_end;
+        bad_cur0 = bad_cur1 = bad_end;
       } else if (cur1 > cur0 && (full(end - cur0, rp_end - rp_cur0) > budget_bytes || end - cur0 > merge_nodes)) {
-        flush(cur0, cur1, rp_cur1 - rp_cur0);
+        flush(cur0, cur1, rp_cur1 - rp_cur0, bad_cur0, bad_cur1);
         cur0 = prev;
         rp_cur0 = rp_prev;
+        bad_cur0 = bad_prev;
         cur1 = end;
         rp_cur1 = rp_end;
+        bad_cur1 = bad_end;
       } else {
-        if (cur1 == cur0) { cur0 = prev; rp_cur0 = rp_prev; }
+        if (cur1 == cur0) { cur0 = prev; rp_cur0 = rp_prev; bad_cur0 = bad_prev; }
         cur1 = end;
         rp_cur1 = rp_end;
+        bad_cur1 = bad_end;
       }
       prev = end;
       rp_prev = rp_end;
+      bad_prev = bad_end;
     }
-    flush(cur0, cur1, rp_cur1 - rp_cur0);
+    };
+    if (cached) walk(std::true_type{});
+    else walk(std::false_type{});
+    flush(cur0, cur1, rp_cur1 - rp_cur0, bad_cur0, bad_cur1);
     hdr[0] = nfit;
     hdr[1] = nspill;
     hdr[2] = maxn;
