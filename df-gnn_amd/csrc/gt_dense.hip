@@ -410,10 +410,12 @@ __device__ __forceinline__ void dense_bwd_body(float *lds, const Csr &g, int n0,
     const int tid = opaque_tid();
 #pragma unroll
     for (int k = 0; k < PRE; ++k) {
-      const unsigned e = (unsigned)min(tid + k * kDenseThreads, eb - ea - 1);  // clamped: plain loads
-      pi[k] = ld32(g.rows + ea, e);
-      pj[k] = ld32(g.col_ind + ea, e);
-      pa[k] = ld32(attn_h + ea, e);
+      // clamped: plain loads (a row block without edges -- rows with in-edges only -- reads the last edge, unused)
+      const unsigned e = (unsigned)min(tid + k * kDenseThreads, max(eb - ea, 1) - 1);
+      const int ea0 = min(ea, g.nnz - 1);
+      pi[k] = ld32(g.rows + ea0, e);
+      pj[k] = ld32(g.col_ind + ea0, e);
+      pa[k] = ld32(attn_h + ea0, e);
     }
   };
   // Zero the tile, scatter P of tile (i0, j0) into it (fp32; edges [ea, eb) are the rows of the row block) and, if
@@ -436,7 +438,7 @@ __device__ __forceinline__ void dense_bwd_body(float *lds, const Csr &g, int n0,
       float ba[B];
 #pragma unroll
       for (int k = 0; k < B; ++k) {
-        const unsigned e = (unsigned)min(base + tid + k * kDenseThreads, eb - ea - 1);
+        const unsigned e = (unsigned)min(base + tid + k * kDenseThreads, eb - ea - 1);  // (eb > ea inside this loop)
         bi[k] = ld32(g.rows + ea, e);
         bj[k] = ld32(g.col_ind + ea, e);
         ba[k] = ld32(attn_h + ea, e);

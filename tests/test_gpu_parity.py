@@ -425,6 +425,9 @@ def test_dense_kernels_every_geometry(oracle_mod, h, f):
         graphs.append(Graph(s_, d_, n))
     s_, d_ = er(70, 0.5, drop_rows=(0, 33, 69))                     # isolated nodes: empty rows and columns
     graphs.append(Graph(s_, d_, 70))
+    keep = rng.random((80, 140)) < 0.3                               # directed: rows 80..139 have in-edges only, so
+    ds_, dd_ = np.nonzero(keep)                                       # the second row block of the backward is empty
+    graphs.append(Graph(ds_.astype(np.int64), dd_.astype(np.int64), 140))
     s_, d_ = er(40, 0.6)
     graphs.append(Graph(np.concatenate([s_, s_[:1]]), np.concatenate([d_, d_[:1]]), 40))   # one duplicate edge
     g = batch(graphs).to(DEV)
