@@ -638,6 +638,10 @@ __device__ __forceinline__ void dense_bwd_body(float *lds, const Csr &g, int n0,
             dense_kblock_mma<F, (NBLK == 1 ? 8 : 4)>(qacc, ihi, ilo, (32 * jb + 8 * L.mq + L.tq) * RS + 4 * L.tp, 4 * RS, sh, sl);
           }
         }
+        if (jc + 1 == NBLK) {  // dQ rows of this row block are complete: store them now, under the dK product
+          const int i = i0 + wave * 16 + L.mi;
+          if (i < i0 + ni) dense_store_acc<FT>(qacc, 1.f, dQb, (unsigned)i * (unsigned)hf + 4u * L.mq, false);
+        }
       }
       DFGNN_DSTAMP(6)
       lds_barrier();  // K image free
@@ -654,11 +658,6 @@ __device__ __forceinline__ void dense_bwd_body(float *lds, const Csr &g, int n0,
       DFGNN_DSTAMP(7)
       column_phase(dKb, j0, ni, !first);
       lds_barrier();  // Q image and dS tile free
-    }
-    if (row_wave) {
-      const LaneIds L = lane_ids();
-      const int i = i0 + wave * 16 + L.mi;
-      if (i < i0 + ni) dense_store_acc<FT>(qacc, 1.f, dQb, (unsigned)i * (unsigned)hf + 4u * L.mq, false);
     }
     DFGNN_DSTAMP(8)
   }
