@@ -1,9 +1,8 @@
 """GAT operator surface -- same names / signatures as the reference's DFGNN/operators/fused_gatconv.py.
 
-In scope: the hyper / softmax / softmax_gm / tiling inference functions.
-`GATConvFuse` / `FusedGATFunction` (dgNN training pair, no live caller in the reference) and the
-hyper_v2 / hyper_recompute experiments are kept as names; their binding entry points raise
-NotImplementedError (SURVEY.md 8f "next").
+In scope: the hyper / softmax / softmax_gm / tiling inference functions and the training
+pair `GATConvFuse` / `FusedGATFunction`.  The hyper_v2 / hyper_recompute experiments are
+kept as names; their binding entry points raise NotImplementedError.
 """
 import fused_gatconv as fused_gat
 import torch
@@ -54,7 +53,7 @@ def GATConvFuse_inference_hyper_v2(smem_consume, a_l, a_r, indptr, indices, nega
 
 
 class FusedGATFunction(torch.autograd.Function):
-    """reference :95-176 (dgNN training pair; next)."""
+    """reference :95-176 (training pair: fwd saves the row statistics, bwd recomputes the attention)."""
 
     @staticmethod
     def forward(ctx, attn_row, attn_col, row_ptr, col_ind, col_ptr, row_ind, permute, negative_slope, in_feat,
@@ -78,6 +77,6 @@ class FusedGATFunction(torch.autograd.Function):
 
 def GATConvFuse(attn_row, attn_col, row_ptr, col_ind, col_ptr, row_ind, permute, negative_slope, in_feat,
                 attn_drop):
-    """reference :5-28 (next)"""
+    """reference :5-28"""
     return FusedGATFunction.apply(attn_row, attn_col, row_ptr, col_ind, col_ptr, row_ind, permute,
                                   negative_slope, in_feat, attn_drop)

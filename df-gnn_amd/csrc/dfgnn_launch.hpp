@@ -127,4 +127,16 @@ int launch_gat_tiling_fwd(const Csr &g, const float *attn_row, const float *attn
 int launch_gat_sddmm(const Csr &g, const float *attn_row, const float *attn_col, float slope, float *logits,
                      hipStream_t s);
 
+// GAT training pair (gat_train.hip)
+int launch_gat_train_fwd(const Csr &g, const float *attn_row, const float *attn_col, float slope, const float *X,
+                         const float *edge_mask, float attn_drop, float *edge_max, float *edge_sum, float *out,
+                         hipStream_t s);
+int launch_gat_bwd_rows(const Csr &g, const float *attn_row, const float *attn_col, float slope, const float *X,
+                        const float *edge_max, const float *edge_sum, const float *edge_mask, float attn_drop,
+                        const float *grad_out, float *grad_edge, float *grad_row, hipStream_t s);
+int launch_gat_bwd_cols(const Csr &g, const int *col_ptr, const int *row_ind, const int *permute,
+                        const float *attn_row, const float *attn_col, float slope, const float *edge_max,
+                        const float *edge_sum, const float *edge_mask, float attn_drop, const float *grad_edge,
+                        const float *grad_out, float *grad_feat, float *grad_col, hipStream_t s);
+
 }  // namespace dfgnn

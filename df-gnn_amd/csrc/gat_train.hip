@@ -1,0 +1,279 @@
+// gat_train.hip -- GAT training pair for gfx950, general kernels (any graph, no degree limit).
+//
+//   gat_train_fwd_kernel   CSR, a wave per row, 64-edge tiles, online softmax; also writes the row statistics the
+//                          backward recomputes P from (edge_max, edge_sum) and applies attention dropout from a
+//                          caller-provided tensor of uniform randoms.  replaces fused_forward_kernel
+//                          (DFGNN/src/fused_gatconv/fused_gatconv_kernel.cu:24-125; launcher :1062-1129)
+//   gat_bwd_rows_kernel    CSR pass: dP_e = <dO[i], X[j]>, g_e = keep_e dP_e / (1 - drop),
+//                          G_e = P_e (g_e - sum_row P g) LeakyReLU'(pre_e) -> grad_edge; grad_attn_row[i] = sum_e G_e.
+//                          replaces mhsddmm + fused_backward_kernel (fused_gatconv_kernel.cu:711-865)
+//   gat_bwd_cols_kernel    CSC pass: grad_feat[j] = sum_{e->j} keep_e P_e / (1 - drop) dO[i],
+//                          grad_attn_col[j] = sum_{e->j} G_e.  replaces mhspmm_backward_kernel (:609-660) and the
+//                          atomicAdd into grad_attn_col (:853): the column sums are deterministic here.
+//
+// Layouts as in the reference: edge_max / edge_sum / attn_row / attn_col fp32[m, h]; edge_mask fp32[nnz, h]
+// (EDGE-major, CSR order, fused_gatconv_kernel.cu:101).  grad_edge is this library's scratch, fp32[h, nnz].
+#include "dfgnn_launch.hpp"
+#include "dfgnn_rows.hpp"
+
+namespace dfgnn {
+
+// d_e = <a, X[cols[e]]> for the nt (<= 64) edges of a tile; lane 0 of each group writes sw[e].  4 gathers in flight.
+template <class C>
+__device__ __forceinline__ void tile_dots(const Frag<C> &a, const int *cols, int nt, const float *__restrict__ X,
+                                          size_t hf, int f, int gid, int gl, float *sw) {
+  int e = gid;
+  for (; e + 3 * C::EPW < nt; e += 4 * C::EPW) {
+    Frag<C> x0, x1, x2, x3;
+    frag_load<C>(x0, X + (size_t)cols[e] * hf, f, gl);
+    frag_load<C>(x1, X + (size_t)cols[e + C::EPW] * hf, f, gl);
+    frag_load<C>(x2, X + (size_t)cols[e + 2 * C::EPW] * hf, f, gl);
+    frag_load<C>(x3, X + (size_t)cols[e + 3 * C::EPW] * hf, f, gl);
+    const float d0 = lanes_sum<C::G>(frag_dot<C>(a, x0)), d1 = lanes_sum<C::G>(frag_dot<C>(a, x1));
+    const float d2 = lanes_sum<C::G>(frag_dot<C>(a, x2)), d3 = lanes_sum<C::G>(frag_dot<C>(a, x3));
+    if (gl == 0) {
+      sw[e] = d0;
+      sw[e + C::EPW] = d1;
+      sw[e + 2 * C::EPW] = d2;
+      sw[e + 3 * C::EPW] = d3;
+    }
+  }
+  for (; e < nt; e += C::EPW) {
+    Frag<C> x0;
+    frag_load<C>(x0, X + (size_t)cols[e] * hf, f, gl);
+    const float d0 = lanes_sum<C::G>(frag_dot<C>(a, x0));
+    if (gl == 0) sw[e] = d0;
+  }
+}
+
+struct GatDrop {         // attention dropout: keep edge e of head hd iff mask[e*h + hd] > drop
+  const float *mask;     // uniform randoms [nnz, h]; NULL = keep everything
+  float drop, scale;     // scale = 1 / (1 - drop)  (1 when mask == NULL)
+};
+
+template <class C>
+__global__ __launch_bounds__(kBlock) void gat_train_fwd_kernel(Csr g, const float *__restrict__ attn_row,
+                                                               const float *__restrict__ attn_col, float slope,
+                                                               const float *__restrict__ X, GatDrop dr,
+                                                               float *__restrict__ edge_max,
+                                                               float *__restrict__ edge_sum,
+                                                               float *__restrict__ out) {
+  __shared__ __attribute__((aligned(16))) float lds[kWavesPerBlock * kScratchFloatsPerWave];
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+  float *sw = lds + wave * kScratchFloatsPerWave;
+  int *sc = reinterpret_cast<int *>(sw + kWave);
+  const int head = blockIdx.y, h = g.h, f = g.f;
+  const size_t hf = (size_t)h * f;
+  const float *Xh = X + (size_t)head * f;
+  const float *acol_h = attn_col + head;
+  const int gid = lane / C::G, gl = lane % C::G;
+  for (int r = blockIdx.x * kWavesPerBlock + wave; r < g.m; r += gridDim.x * kWavesPerBlock) {
+    const int lb = g.row_ptr[r], deg = g.row_ptr[r + 1] - lb;
+    const float ar = attn_row[(size_t)r * h + head];
+    Frag<C> acc;
+    frag_zero<C>(acc);
+    float m_run = -INFINITY, l_run = 0.f;
+    for (int t0 = 0; t0 < deg; t0 += kWave) {
+      const int nt = min(kWave, deg - t0);
+      float s = -INFINITY;
+      int c = 0;
+      bool keep = true;
+      if (lane < nt) {
+        c = g.col_ind[lb + t0 + lane];
+        s = leaky_relu(ar + acol_h[(size_t)c * h], slope);
+        if (dr.mask) keep = dr.mask[(size_t)(lb + t0 + lane) * h + head] > dr.drop;
+      }
+      sc[lane] = c;
+      online_step<C>(s, lane, sw, acc, m_run, l_run);  // the row sum counts every edge, dropped or not
+      if (!keep) sw[lane] = 0.f;
+      wave_sync();
+      spmm_accum<C>(acc, sw, sc, nt, Xh, hf, f, gid, gl);
+      wave_sync();
+    }
+    const float inv = (l_run != 0.f) ? dr.scale / l_run : 0.f;
+    frag_reduce_groups<C>(acc);
+    if (gid == 0) frag_store_scaled<C>(acc, inv, out + (size_t)r * hf + (size_t)head * f, f, gl);
+    if (lane == 0) {
+      edge_max[(size_t)r * h + head] = deg > 0 ? m_run : -1e38f;  // the reference's sentinel (:46, :66)
+      edge_sum[(size_t)r * h + head] = l_run;
+    }
+  }
+}
+
+template <class C>
+__global__ __launch_bounds__(kBlock) void gat_bwd_rows_kernel(Csr g, const float *__restrict__ attn_row,
+                                                              const float *__restrict__ attn_col, float slope,
+                                                              const float *__restrict__ X,
+                                                              const float *__restrict__ edge_max,
+                                                              const float *__restrict__ edge_sum, GatDrop dr,
+                                                              const float *__restrict__ dO,
+                                                              float *__restrict__ grad_edge,
+                                                              float *__restrict__ grad_row) {
+  __shared__ __attribute__((aligned(16))) float lds[kWavesPerBlock * kScratchFloatsPerWave];
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+  float *sw = lds + wave * kScratchFloatsPerWave;
+  int *sc = reinterpret_cast<int *>(sw + kWave);
+  const int head = blockIdx.y, h = g.h, f = g.f;
+  const size_t hf = (size_t)h * f;
+  const float *Xh = X + (size_t)head * f, *dOh = dO + (size_t)head * f;
+  const float *acol_h = attn_col + head;
+  float *G_h = grad_edge + (size_t)head * g.nnz;
+  const int gid = lane / C::G, gl = lane % C::G;
+  for (int r = blockIdx.x * kWavesPerBlock + wave; r < g.m; r += gridDim.x * kWavesPerBlock) {
+    const int lb = g.row_ptr[r], deg = g.row_ptr[r + 1] - lb;
+    float rs = 0.f;
+    if (deg > 0) {
+      const float ar = attn_row[(size_t)r * h + head];
+      const float mx = edge_max[(size_t)r * h + head], inv = 1.f / edge_sum[(size_t)r * h + head];
+      Frag<C> go;
+      frag_load<C>(go, dOh + (size_t)r * hf, f, gl);
+      // sweep 1: g_e and t = sum_e P_e g_e.  Single-tile rows keep (P, g, slope factor) in registers; longer rows
+      // park g_e in grad_edge and recompute P in sweep 2.
+      float t = 0.f, p_keep = 0.f, g_keep = 0.f, lr_keep = 0.f;
+      for (int t0 = 0; t0 < deg; t0 += kWave) {
+        const int nt = min(kWave, deg - t0);
+        int c = 0;
+        if (lane < nt) c = g.col_ind[lb + t0 + lane];
+        sc[lane] = c;
+        wave_sync();
+        tile_dots<C>(go, sc, nt, Xh, hf, f, gid, gl, sw);
+        wave_sync();
+        if (lane < nt) {
+          const int e = lb + t0 + lane;
+          const float pre = ar + acol_h[(size_t)c * h];
+          const float p = fast_exp(leaky_relu(pre, slope) - mx) * inv;
+          const bool keep = dr.mask ? dr.mask[(size_t)e * h + head] > dr.drop : true;
+          const float ge = keep ? sw[lane] * dr.scale : 0.f;
+          t = fmaf(p, ge, t);
+          p_keep = p;
+          g_keep = ge;
+          lr_keep = pre > 0.f ? 1.f : slope;
+          if (deg > kWave) G_h[e] = ge;
+        }
+        wave_sync();
+      }
+      t = lanes_sum<kWave>(t);
+      if (deg <= kWave) {
+        float ge = 0.f;
+        if (lane < deg) {
+          ge = p_keep * (g_keep - t) * lr_keep;
+          G_h[lb + lane] = ge;
+        }
+        rs = lanes_sum<kWave>(ge);
+      } else {
+        for (int e = lb + lane; e < lb + deg; e += kWave) {
+          const float pre = ar + acol_h[(size_t)g.col_ind[e] * h];
+          const float p = fast_exp(leaky_relu(pre, slope) - mx) * inv;
+          const float ge = p * (G_h[e] - t) * (pre > 0.f ? 1.f : slope);  // this lane parked G_h[e] in sweep 1
+          G_h[e] = ge;
+          rs += ge;
+        }
+        rs = lanes_sum<kWave>(rs);
+      }
+    }
+    if (lane == 0) grad_row[(size_t)r * h + head] = rs;
+  }
+}
+
+template <class C>
+__global__ __launch_bounds__(kBlock) void gat_bwd_cols_kernel(Csr g, const int *__restrict__ col_ptr,
+                                                              const int *__restrict__ row_ind,
+                                                              const int *__restrict__ permute,
+                                                              const float *__restrict__ attn_row,
+                                                              const float *__restrict__ attn_col, float slope,
+                                                              const float *__restrict__ edge_max,
+                                                              const float *__restrict__ edge_sum, GatDrop dr,
+                                                              const float *__restrict__ grad_edge,
+                                                              const float *__restrict__ dO,
+                                                              float *__restrict__ grad_feat,
+                                                              float *__restrict__ grad_col) {
+  __shared__ __attribute__((aligned(16))) float lds[kWavesPerBlock * kScratchFloatsPerWave];
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+  float *sw = lds + wave * kScratchFloatsPerWave;
+  int *sc = reinterpret_cast<int *>(sw + kWave);
+  const int head = blockIdx.y, h = g.h, f = g.f;
+  const size_t hf = (size_t)h * f;
+  const float *dOh = dO + (size_t)head * f;
+  const float *arow_h = attn_row + head, *mx_h = edge_max + head, *sum_h = edge_sum + head;
+  const float *G_h = grad_edge + (size_t)head * g.nnz;
+  const int gid = lane / C::G, gl = lane % C::G;
+  for (int j = blockIdx.x * kWavesPerBlock + wave; j < g.m; j += gridDim.x * kWavesPerBlock) {
+    const int lb = col_ptr[j], n = col_ptr[j + 1] - lb;
+    const float ac = attn_col[(size_t)j * h + head];
+    Frag<C> acc;
+    frag_zero<C>(acc);
+    float gs = 0.f;
+    for (int t0 = 0; t0 < n; t0 += kWave) {
+      const int nt = min(kWave, n - t0);
+      float w = 0.f;
+      int i = 0;
+      if (lane < nt) {
+        i = row_ind[lb + t0 + lane];
+        const int e = permute[lb + t0 + lane];
+        const float pre = arow_h[(size_t)i * h] + ac;
+        const float p = fast_exp(leaky_relu(pre, slope) - mx_h[(size_t)i * h]) / sum_h[(size_t)i * h];
+        const bool keep = dr.mask ? dr.mask[(size_t)e * h + head] > dr.drop : true;
+        w = keep ? p * dr.scale : 0.f;
+        gs += G_h[e];
+      }
+      sw[lane] = w;
+      sc[lane] = i;
+      wave_sync();
+      spmm_accum<C>(acc, sw, sc, nt, dOh, hf, f, gid, gl);
+      wave_sync();
+    }
+    frag_reduce_groups<C>(acc);
+    if (gid == 0) frag_store_scaled<C>(acc, 1.f, grad_feat + (size_t)j * hf + (size_t)head * f, f, gl);
+    gs = lanes_sum<kWave>(gs);
+    if (lane == 0) grad_col[(size_t)j * h + head] = gs;
+  }
+}
+
+static inline int row_grid(int m) {
+  const long want = ((long)m + kWavesPerBlock - 1) / kWavesPerBlock;
+  return (int)(want > (1 << 20) ? (1 << 20) : want);
+}
+
+int launch_gat_train_fwd(const Csr &g, const float *attn_row, const float *attn_col, float slope, const float *X,
+                         const float *edge_mask, float attn_drop, float *edge_max, float *edge_sum, float *out,
+                         hipStream_t s) {
+  const dim3 grid(row_grid(g.m), g.h);
+  const GatDrop dr{edge_mask, attn_drop, edge_mask ? 1.f / (1.f - attn_drop) : 1.f};
+  const bool v4 = (g.f % 4 == 0) && aligned16(X) && aligned16(out);
+  return dispatch_cfg(g.f, v4, [&](auto cfg) {
+    using C = decltype(cfg);
+    gat_train_fwd_kernel<C><<<grid, kBlock, 0, s>>>(g, attn_row, attn_col, slope, X, dr, edge_max, edge_sum, out);
+    return launch_status();
+  });
+}
+
+int launch_gat_bwd_rows(const Csr &g, const float *attn_row, const float *attn_col, float slope, const float *X,
+                        const float *edge_max, const float *edge_sum, const float *edge_mask, float attn_drop,
+                        const float *grad_out, float *grad_edge, float *grad_row, hipStream_t s) {
+  const dim3 grid(row_grid(g.m), g.h);
+  const GatDrop dr{edge_mask, attn_drop, edge_mask ? 1.f / (1.f - attn_drop) : 1.f};
+  const bool v4 = (g.f % 4 == 0) && aligned16(X) && aligned16(grad_out);
+  return dispatch_cfg(g.f, v4, [&](auto cfg) {
+    using C = decltype(cfg);
+    gat_bwd_rows_kernel<C><<<grid, kBlock, 0, s>>>(g, attn_row, attn_col, slope, X, edge_max, edge_sum, dr,
+                                                   grad_out, grad_edge, grad_row);
+    return launch_status();
+  });
+}
+
+int launch_gat_bwd_cols(const Csr &g, const int *col_ptr, const int *row_ind, const int *permute,
+                        const float *attn_row, const float *attn_col, float slope, const float *edge_max,
+                        const float *edge_sum, const float *edge_mask, float attn_drop, const float *grad_edge,
+                        const float *grad_out, float *grad_feat, float *grad_col, hipStream_t s) {
+  const dim3 grid(row_grid(g.m), g.h);
+  const GatDrop dr{edge_mask, attn_drop, edge_mask ? 1.f / (1.f - attn_drop) : 1.f};
+  const bool v4 = (g.f % 4 == 0) && aligned16(grad_out) && aligned16(grad_feat);
+  return dispatch_cfg(g.f, v4, [&](auto cfg) {
+    using C = decltype(cfg);
+    gat_bwd_cols_kernel<C><<<grid, kBlock, 0, s>>>(g, col_ptr, row_ind, permute, attn_row, attn_col, slope,
+                                                   edge_max, edge_sum, dr, grad_edge, grad_out, grad_feat, grad_col);
+    return launch_status();
+  });
+}
+
+}  // namespace dfgnn

@@ -3,9 +3,9 @@
 MI355X HIP library through its C ABI (include/dfgnn.h).  See fused_gtconv.py for the conventions.
 
 In scope: the four inference entry points of the hyper / softmax /
-softmax_gm / tiling variants.  The dgNN-inherited training pair gat_forward / gat_backward and the
-experimental hyper_v2 / hyper_recompute / tb entry points are "next"  and raise
-NotImplementedError rather than pretending.
+softmax_gm / tiling variants, and the training pair gat_forward / gat_backward
+behind FusedGATFunction.  The experimental hyper_v2 / hyper_recompute / tb entry points are "next"
+ and raise NotImplementedError rather than pretending.
 """
 import torch
 
@@ -108,8 +108,74 @@ def _next(name):
     return fn
 
 
-gat_forward = _next("gat_forward")
-gat_backward = _next("gat_backward")
+def gat_forward(attn_row, attn_col, row_ptr, col_ind, negative_slope, in_feat, attn_drop):
+    """fused_gatconv.cpp:11-32 -> [out_feat[m,h,f], edge_max[m,h], edge_sum[m,h], edge_mask[nnz,h]]
+
+    edge_mask holds the uniform randoms of the attention dropout (the reference fills it with cuRAND seeded by
+    clock(), fused_gatconv_kernel.cu:1074-1083; here torch.rand, so torch.manual_seed reproduces a run).  With
+    attn_drop == 0 nothing is dropped and no randoms are drawn: edge_mask is then a stride-0 view of a single 1.0
+    (same shape, no memory), which gat_backward accepts for attn_drop == 0."""
+    m, nnz, h, f = _check(attn_row, attn_col, row_ptr, col_ind, None, in_feat)
+    attn_drop = float(attn_drop)
+    if not 0.0 <= attn_drop < 1.0:
+        raise RuntimeError(f"attn_drop must be in [0, 1), got {attn_drop}")
+    dev = in_feat.device
+    with torch.cuda.device(dev):
+        out = torch.empty_like(in_feat)
+        edge_max = torch.empty((m, h), dtype=torch.float32, device=dev)
+        edge_sum = torch.empty((m, h), dtype=torch.float32, device=dev)
+        if attn_drop > 0.0:
+            edge_mask = torch.rand((nnz, h), dtype=torch.float32, device=dev)
+            mask_ptr = ptr(edge_mask)
+        else:
+            edge_mask = torch.ones((1, 1), dtype=torch.float32, device=dev).expand(nnz, h)
+            mask_ptr = None
+        _n.check(_n.lib().dfgnn_gat_fwd_train(m, nnz, h, f, ptr(row_ptr), ptr(col_ind), ptr(attn_row),
+                                              ptr(attn_col), float(negative_slope), ptr(in_feat), mask_ptr,
+                                              attn_drop, ptr(edge_max), ptr(edge_sum), ptr(out), stream_ptr(dev)),
+                 "gat_forward")
+    return [out, edge_max, edge_sum, edge_mask]
+
+
+def gat_backward(negative_slope, attn_drop, row_ptr, col_ind, col_ptr, row_ind, permute, edge_max, edge_sum,
+                 edge_mask, in_feat, attn_row, attn_col, grad):
+    """fused_gatconv.cpp:291-353 -> [grad_feat[m,h,f], grad_attn_row[m,h], grad_attn_col[m,h]]"""
+    m, nnz, h, f = _check(attn_row, attn_col, row_ptr, col_ind, None, in_feat)
+    attn_drop = float(attn_drop)
+    if not 0.0 <= attn_drop < 1.0:
+        raise RuntimeError(f"attn_drop must be in [0, 1), got {attn_drop}")
+    tensors = dict(col_ptr=col_ptr, row_ind=row_ind, permute=permute, edge_max=edge_max, edge_sum=edge_sum,
+                   grad=grad)
+    check_device(edge_mask=edge_mask, **tensors)
+    check_contiguous(**tensors)
+    check_dtype(torch.int32, col_ptr=col_ptr, row_ind=row_ind, permute=permute)
+    check_dtype(torch.float32, edge_max=edge_max, edge_sum=edge_sum, edge_mask=edge_mask, grad=grad)
+    if grad.shape != in_feat.shape:
+        raise RuntimeError(f"grad has shape {tuple(grad.shape)}, expected {tuple(in_feat.shape)}")
+    if tuple(edge_max.shape) != (m, h) or tuple(edge_sum.shape) != (m, h):
+        raise RuntimeError(f"edge_max / edge_sum must have shape ({m}, {h})")
+    if col_ptr.size(0) != m + 1 or row_ind.size(0) != nnz or permute.size(0) != nnz:
+        raise RuntimeError("col_ptr / row_ind / permute do not match the CSR structure")
+    mask_ptr = None
+    if attn_drop > 0.0:
+        if tuple(edge_mask.shape) != (nnz, h):
+            raise RuntimeError(f"edge_mask must have shape ({nnz}, {h}), got {tuple(edge_mask.shape)}")
+        check_contiguous(edge_mask=edge_mask)
+        mask_ptr = ptr(edge_mask)
+    dev = in_feat.device
+    with torch.cuda.device(dev):
+        grad_feat = torch.empty_like(in_feat)
+        grad_attn_row = torch.empty((m, h), dtype=torch.float32, device=dev)
+        grad_attn_col = torch.empty((m, h), dtype=torch.float32, device=dev)
+        grad_edge = torch.empty((h, nnz), dtype=torch.float32, device=dev)
+        _n.check(_n.lib().dfgnn_gat_bwd(m, nnz, h, f, ptr(row_ptr), ptr(col_ind), ptr(col_ptr), ptr(row_ind),
+                                        ptr(permute), ptr(attn_row), ptr(attn_col), float(negative_slope),
+                                        ptr(in_feat), ptr(edge_max), ptr(edge_sum), mask_ptr, attn_drop, ptr(grad),
+                                        ptr(grad_edge), ptr(grad_feat), ptr(grad_attn_row), ptr(grad_attn_col),
+                                        stream_ptr(dev)), "gat_backward")
+    return [grad_feat, grad_attn_row, grad_attn_col]
+
+
 gat_forward_tb = _next("gat_forward_tb")
 gat_inference_hyper_v2 = _next("gat_inference_hyper_v2")
 gat_inference_hyper_recompute = _next("gat_inference_hyper_recompute")

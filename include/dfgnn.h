@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define DFGNN_ABI_VERSION 5
+#define DFGNN_ABI_VERSION 6
 
 #define DFGNN_E_BADARG (-1)      /* negative size / NULL required pointer                      */
 #define DFGNN_E_UNSUPPORTED (-2) /* feature width outside the compiled range (f > 1024, or     */
@@ -147,6 +147,33 @@ int dfgnn_gat_softmax_gm_fwd(int m, int nnz, int h, int f, const int *row_ptr, c
 int dfgnn_gat_tiling_fwd(int m, int nnz, int h, int f, const int *row_ptr, const int *col_ind,
                          const float *attn_row, const float *attn_col, float negative_slope,
                          const float *X, float *out, dfgnn_stream_t stream);
+
+/* ---- GAT training pair (FusedGATFunction, DFGNN/operators/fused_gatconv.py:95-176) --------------------
+ * edge_max, edge_sum fp32[m, h]: per-row maximum of the LeakyReLU logits (-1e38 for an empty row) and
+ *   sum_e exp(s_e - max); the backward recomputes P_e from them, as the reference does.
+ * edge_mask fp32[nnz, h], EDGE-major (index e*h + head, fused_gatconv_kernel.cu:101): uniform randoms for
+ *   attention dropout, an INPUT here (the reference draws it inside with cuRAND seeded by clock(),
+ *   fused_gatconv_kernel.cu:1074-1083; the binding draws it with torch.rand so runs are reproducible).
+ *   Edge e of head hd is kept iff edge_mask[e*h + hd] > attn_drop and its attention is scaled by
+ *   1 / (1 - attn_drop).  NULL = no dropout (attn_drop is then ignored); with a mask, 0 <= attn_drop < 1.
+ *
+ * dfgnn_gat_fwd_train replaces gat_forward (fused_gatconv.cpp:11-32, fused_gatconv_kernel.cu:24-125, 1062-1129):
+ *   CSR only; writes out[m, h, f], edge_max, edge_sum. */
+int dfgnn_gat_fwd_train(int m, int nnz, int h, int f, const int *row_ptr, const int *col_ind,
+                        const float *attn_row, const float *attn_col, float negative_slope,
+                        const float *X, const float *edge_mask, float attn_drop, float *edge_max,
+                        float *edge_sum, float *out, dfgnn_stream_t stream);
+
+/* replaces gat_backward (fused_gatconv.cpp:291-353, fused_gatconv_kernel.cu:609-865, 1172-1244).
+ * col_ptr int32[m+1], row_ind int32[nnz], permute int32[nnz] (CSR slot of each CSC entry; the GT path calls
+ * it val_idx).  grad_edge: caller scratch fp32[h, nnz].  Writes grad_feat fp32[m, h, f], grad_attn_row and
+ * grad_attn_col fp32[m, h] in full (no pre-zeroing, no atomics: the column sums are deterministic). */
+int dfgnn_gat_bwd(int m, int nnz, int h, int f, const int *row_ptr, const int *col_ind,
+                  const int *col_ptr, const int *row_ind, const int *permute, const float *attn_row,
+                  const float *attn_col, float negative_slope, const float *X, const float *edge_max,
+                  const float *edge_sum, const float *edge_mask, float attn_drop,
+                  const float *grad_out, float *grad_edge, float *grad_feat, float *grad_attn_row,
+                  float *grad_attn_col, dfgnn_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -111,6 +111,47 @@ def gat_forward(indptr, indices, attn_row, attn_col, negative_slope, X, want_att
     return (out, attn) if want_attn else out
 
 
+def gat_train_forward(indptr, indices, attn_row, attn_col, negative_slope, X, edge_mask=None, attn_drop=0.0,
+                      acc="f64"):
+    """Oracle of ``gat_forward`` (FusedGATFunction.forward, DFGNN/operators/fused_gatconv.py:95-127): returns
+    ``(out[m,h,f], edge_max[m,h], edge_sum[m,h])``.  ``edge_mask`` is the uniform-random tensor ``[nnz, h]`` the
+    reference draws with cuRAND (an input here, so results are reproducible); ``None`` = no dropout."""
+    sfx, dt = _acc(acc)
+    indptr, indices = _i32(indptr), _i32(indices)
+    attn_row, attn_col, X = _f32(attn_row), _f32(attn_col), _f32(X)
+    mask = _f32(edge_mask) if edge_mask is not None else None
+    m, nnz = indptr.shape[0] - 1, indices.shape[0]
+    _, h, f = X.shape
+    out = np.empty((m, h, f), dtype=dt)
+    emax = np.empty((m, h), dtype=dt)
+    esum = np.empty((m, h), dtype=dt)
+    getattr(_lib(), "oracle_gat_train_forward" + sfx)(
+        ctypes.c_int(m), ctypes.c_int(nnz), ctypes.c_int(h), ctypes.c_int(f),
+        _p(indptr), _p(indices), _p(attn_row), _p(attn_col), ctypes.c_float(negative_slope),
+        _p(X), _p(mask), ctypes.c_float(attn_drop), _p(out), _p(emax), _p(esum))
+    return out, emax, esum
+
+
+def gat_backward(indptr, indices, attn_row, attn_col, negative_slope, X, dO, edge_mask=None, attn_drop=0.0,
+                 acc="f64"):
+    """Oracle of ``gat_backward``: returns ``(grad_feat[m,h,f], grad_attn_row[m,h], grad_attn_col[m,h])``
+    (FusedGATFunction.backward, DFGNN/operators/fused_gatconv.py:129-176)."""
+    sfx, dt = _acc(acc)
+    indptr, indices = _i32(indptr), _i32(indices)
+    attn_row, attn_col, X, dO = _f32(attn_row), _f32(attn_col), _f32(X), _f32(dO)
+    mask = _f32(edge_mask) if edge_mask is not None else None
+    m, nnz = indptr.shape[0] - 1, indices.shape[0]
+    _, h, f = X.shape
+    gf = np.empty((m, h, f), dtype=dt)
+    gr = np.empty((m, h), dtype=dt)
+    gc = np.empty((m, h), dtype=dt)
+    getattr(_lib(), "oracle_gat_backward" + sfx)(
+        ctypes.c_int(m), ctypes.c_int(nnz), ctypes.c_int(h), ctypes.c_int(f),
+        _p(indptr), _p(indices), _p(attn_row), _p(attn_col), ctypes.c_float(negative_slope),
+        _p(X), _p(mask), ctypes.c_float(attn_drop), _p(dO), _p(gf), _p(gr), _p(gc))
+    return gf, gr, gc
+
+
 # ---- preprocessing oracle (layers/util.py:82-142 of the reference, restated with numpy) -------
 def coo_to_hyper(src, dst, num_nodes):
     """(src, dst) edge list -> dict with the reference's preprocess_Hyper_fw_bw arrays.

@@ -230,3 +230,124 @@ void FN(oracle_gat_forward)(int m, int nnz, int h, int f, const int32_t *indptr,
     free(s);
   }
 }
+
+/* ---- GAT training pair ---------------------------------------------------
+ * Math of FusedGATFunction (DFGNN/operators/fused_gatconv.py:95-176) -> gat_forward / gat_backward
+ * (DFGNN/src/fused_gatconv/fused_gatconv.cpp:11-32, 291-353; fused_gatconv_kernel.cu:24-125, 609-865):
+ *   pre_e = attn_row[i,h] + attn_col[j,h];  s_e = LeakyReLU(pre_e);  P = row softmax(s)
+ *   edge_max[i,h] = max_e s_e (-1e38 for an empty row), edge_sum[i,h] = sum_e exp(s_e - max)   (:66-67, :89-90)
+ *   keep_e = edge_mask[e,h] > attn_drop (edge_mask: uniform randoms, [nnz, h] EDGE-major; NULL = keep all)
+ *   Pd_e = keep_e ? P_e / (1 - attn_drop) : 0                                                 (:101-110)
+ *   out[i,h,:] = sum_e Pd_e X[j,h,:]
+ * backward (dropout is applied AFTER the softmax, so the softmax Jacobian sees g_e = keep_e dP_e/(1-drop)):
+ *   dP_e = <dO[i,h,:], X[j,h,:]>  (mhsddmm :711-787);  g_e = keep_e ? dP_e / (1 - drop) : 0    (:817-819)
+ *   dS_e = P_e (g_e - sum_row P g)                                                            (:820, :848)
+ *   G_e  = dS_e * (pre_e > 0 ? 1 : slope)     (the reference tests s_e < 0, :849; same away from pre_e == 0)
+ *   grad_attn_row[i,h] = sum_{e in row i} G_e (:863);  grad_attn_col[j,h] = sum_{e -> j} G_e (atomicAdd :853)
+ *   grad_feat[j,h,:]   = sum_{e -> j} Pd_e dO[i,h,:]                                          (:609-660)
+ * grad_feat / grad_attn_col are accumulated serially per head in edge order (deterministic). */
+void FN(oracle_gat_train_forward)(int m, int nnz, int h, int f, const int32_t *indptr, const int32_t *indices,
+                                  const float *attn_row, const float *attn_col, float negative_slope,
+                                  const float *X, const float *edge_mask, float attn_drop, acc_t *out,
+                                  acc_t *edge_max, acc_t *edge_sum) {
+  (void)nnz;
+  const size_t hf = (size_t)h * f;
+  const acc_t keep_scale = (acc_t)1 / ((acc_t)1 - (acc_t)attn_drop);
+#pragma omp parallel for schedule(dynamic, 64)
+  for (int i = 0; i < m; ++i) {
+    const int lb = indptr[i], deg = indptr[i + 1] - lb;
+    for (int hh = 0; hh < h; ++hh) {
+      const acc_t ar = (acc_t)attn_row[(size_t)i * h + hh];
+      acc_t mx = (acc_t)-1e38, sum = 0;
+      for (int e = 0; e < deg; ++e) {
+        acc_t w = ar + (acc_t)attn_col[(size_t)indices[lb + e] * h + hh];
+        w = w > 0 ? w : w * (acc_t)negative_slope;
+        if (w > mx) mx = w;
+      }
+      for (int e = 0; e < deg; ++e) {
+        acc_t w = ar + (acc_t)attn_col[(size_t)indices[lb + e] * h + hh];
+        w = w > 0 ? w : w * (acc_t)negative_slope;
+        sum += exp(w - mx);
+      }
+      edge_max[(size_t)i * h + hh] = mx;
+      edge_sum[(size_t)i * h + hh] = sum;
+      acc_t *o = out + (size_t)i * hf + (size_t)hh * f;
+      for (int c = 0; c < f; ++c) o[c] = 0;
+      for (int e = 0; e < deg; ++e) {
+        if (edge_mask && !(edge_mask[(size_t)(lb + e) * h + hh] > attn_drop)) continue;
+        acc_t w = ar + (acc_t)attn_col[(size_t)indices[lb + e] * h + hh];
+        w = w > 0 ? w : w * (acc_t)negative_slope;
+        const acc_t p = exp(w - mx) / sum * (edge_mask ? keep_scale : (acc_t)1);
+        const float *x = X + (size_t)indices[lb + e] * hf + (size_t)hh * f;
+        for (int c = 0; c < f; ++c) o[c] += p * (acc_t)x[c];
+      }
+    }
+  }
+}
+
+void FN(oracle_gat_backward)(int m, int nnz, int h, int f, const int32_t *indptr, const int32_t *indices,
+                             const float *attn_row, const float *attn_col, float negative_slope, const float *X,
+                             const float *edge_mask, float attn_drop, const float *dO, acc_t *grad_feat,
+                             acc_t *grad_row, acc_t *grad_col) {
+  const int md = max_degree(m, indptr);
+  const size_t hf = (size_t)h * f;
+  const acc_t keep_scale = edge_mask ? (acc_t)1 / ((acc_t)1 - (acc_t)attn_drop) : (acc_t)1;
+  acc_t *Pd = (acc_t *)malloc(sizeof(acc_t) * (size_t)(nnz > 0 ? nnz : 1) * h);
+  acc_t *G = (acc_t *)malloc(sizeof(acc_t) * (size_t)(nnz > 0 ? nnz : 1) * h);
+  for (size_t k = 0; k < (size_t)m * hf; ++k) grad_feat[k] = 0;
+  for (size_t k = 0; k < (size_t)m * h; ++k) grad_row[k] = grad_col[k] = 0;
+#pragma omp parallel
+  {
+    acc_t *s = (acc_t *)malloc(sizeof(acc_t) * (size_t)(md > 0 ? md : 1));
+    acc_t *g = (acc_t *)malloc(sizeof(acc_t) * (size_t)(md > 0 ? md : 1));
+#pragma omp for schedule(dynamic, 64)
+    for (int i = 0; i < m; ++i) {
+      const int lb = indptr[i], deg = indptr[i + 1] - lb;
+      for (int hh = 0; hh < h; ++hh) {
+        const acc_t ar = (acc_t)attn_row[(size_t)i * h + hh];
+        for (int e = 0; e < deg; ++e) {
+          const acc_t pre = ar + (acc_t)attn_col[(size_t)indices[lb + e] * h + hh];
+          s[e] = pre > 0 ? pre : pre * (acc_t)negative_slope;
+        }
+        row_softmax(s, deg);
+        const float *go = dO + (size_t)i * hf + (size_t)hh * f;
+        acc_t t = 0;
+        for (int e = 0; e < deg; ++e) {
+          const int keep = !edge_mask || edge_mask[(size_t)(lb + e) * h + hh] > attn_drop;
+          const float *x = X + (size_t)indices[lb + e] * hf + (size_t)hh * f;
+          acc_t d = 0;
+          for (int c = 0; c < f; ++c) d += (acc_t)go[c] * (acc_t)x[c];
+          g[e] = keep ? d * keep_scale : 0;
+          Pd[(size_t)hh * nnz + lb + e] = keep ? s[e] * keep_scale : 0;
+          t += s[e] * g[e];
+        }
+        acc_t rs = 0;
+        for (int e = 0; e < deg; ++e) {
+          const acc_t pre = ar + (acc_t)attn_col[(size_t)indices[lb + e] * h + hh];
+          const acc_t ge = s[e] * (g[e] - t) * (pre > 0 ? (acc_t)1 : (acc_t)negative_slope);
+          G[(size_t)hh * nnz + lb + e] = ge;
+          rs += ge;
+        }
+        grad_row[(size_t)i * h + hh] = rs;
+      }
+    }
+    free(s);
+    free(g);
+  }
+  /* column side: serial over edges per head (deterministic accumulation order) */
+#pragma omp parallel for schedule(static)
+  for (int hh = 0; hh < h; ++hh) {
+    for (int i = 0; i < m; ++i) {
+      const float *go = dO + (size_t)i * hf + (size_t)hh * f;
+      for (int e = indptr[i]; e < indptr[i + 1]; ++e) {
+        const int j = indices[e];
+        const acc_t p = Pd[(size_t)hh * nnz + e];
+        acc_t *gx = grad_feat + (size_t)j * hf + (size_t)hh * f;
+        for (int c = 0; c < f; ++c) gx[c] += p * (acc_t)go[c];
+        grad_col[(size_t)j * h + hh] += G[(size_t)hh * nnz + e];
+      }
+    }
+  }
+  free(Pd);
+  free(G);
+}

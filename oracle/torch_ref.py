@@ -70,3 +70,26 @@ def gat_forward(indptr, indices, attn_row, attn_col, negative_slope, X, dtype=to
     out, attn = gat_conv(row, col, torch.as_tensor(attn_row).to(dtype), torch.as_tensor(attn_col).to(dtype),
                          negative_slope, torch.as_tensor(X).to(dtype))
     return out, attn.t().contiguous()
+
+
+def gat_train(indptr, indices, attn_row, attn_col, negative_slope, X, dO=None, edge_mask=None, attn_drop=0.0,
+              dtype=torch.float64):
+    """GAT training pair as edge-list algebra + autograd: softmax, then (optionally) attention dropout with the
+    given uniform randoms ``edge_mask[nnz, h]`` (keep where mask > attn_drop, scale 1/(1-attn_drop);
+    DFGNN/src/fused_gatconv/fused_gatconv_kernel.cu:101-110), then spmm.  Returns ``out`` and, when ``dO`` is
+    given, ``(grad_feat, grad_attn_row, grad_attn_col)``."""
+    row, col = csr_to_coo(indptr, indices)
+    ar, ac, Xt = (torch.as_tensor(x).to(dtype).clone().requires_grad_(dO is not None)
+                  for x in (attn_row, attn_col, X))
+    slope = float(torch.tensor(negative_slope, dtype=torch.float32))
+    a = torch.nn.functional.leaky_relu(ar[row] + ac[col], slope)
+    attn = _segment_softmax(a, row, Xt.shape[0])
+    if edge_mask is not None:
+        drop = float(torch.tensor(attn_drop, dtype=torch.float32))
+        keep = (torch.as_tensor(edge_mask, dtype=torch.float32) > drop).to(dtype)
+        attn = attn * keep / (1.0 - drop)
+    out = torch.zeros_like(Xt).index_add_(0, row, attn.unsqueeze(-1) * Xt[col])
+    if dO is None:
+        return out.detach()
+    out.backward(torch.as_tensor(dO).to(dtype))
+    return out.detach(), Xt.grad, ar.grad, ac.grad

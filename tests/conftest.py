@@ -38,6 +38,16 @@ def golden():
     return out
 
 
+@pytest.fixture(scope="session")
+def golden_gat_train(golden):
+    """GAT training-pair expectations for the fixtures of `golden` (tests/golden/make_golden_gat_train.py)."""
+    d = os.path.join(GOLDEN_DIR, "gat_train")
+    out = {fn[:-4]: dict(np.load(os.path.join(d, fn), allow_pickle=False)) for fn in sorted(os.listdir(d))
+           if fn.endswith(".npz")}
+    assert sorted(out) == sorted(golden), "gat_train fixtures out of step with tests/golden/*.npz"
+    return out
+
+
 # ---- tiny graph builders shared by CPU and GPU tests ------------------------------------------
 def random_graph(rng, m, avg_deg, empty_frac=0.0, dup_frac=0.0, max_deg=None):
     """Random CSR graph (int32) with optional empty rows / duplicate edges / one heavy row."""

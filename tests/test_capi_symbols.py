@@ -27,7 +27,7 @@ def test_loader_signatures_cover_header():
     compute = [n for n in _declared() if n not in ("dfgnn_abi_version", "dfgnn_error_string", "dfgnn_plan_ints")]
     assert sorted(dfgnn_native.SIGNATURES) == compute
     lib = dfgnn_native.lib()
-    assert lib.dfgnn_abi_version() == 5
+    assert lib.dfgnn_abi_version() == 6
     assert b"bad argument" in lib.dfgnn_error_string(-1)
     assert b"unsupported" in lib.dfgnn_error_string(-2)
     assert lib.dfgnn_plan_ints(10) == 12 + 8 * 10 + 2

@@ -506,3 +506,103 @@ def test_block_plan_mixed_fit_and_spill(oracle_mod):
     ar, ac, X = S.gat_features(m, 1, 128, seed=6, device=DEV)
     want_gat = oracle_mod.gat_forward(n(row_ptr), n(col_ind), n(ar), n(ac), 0.2, n(X))
     _close(gat.gat_inference_hyper(smem, ar, ac, row_ptr, col_ind, rows, 0.2, X), want_gat, "mixed GAT hyper")
+
+
+# ---- GAT training pair: gat_forward / gat_backward behind FusedGATFunction -------------
+def _gat_train_case(oracle_mod, g, attn_drop, seed=0):
+    """Run GATConvFuse fwd+bwd on CSR/CSC arrays of dict g (numpy); the dropout randoms drawn by the binding are
+    read back and handed to the oracle, so both sides drop the same edges."""
+    import fused_gatconv as gat
+    from DFGNN.operators.fused_gatconv import GATConvFuse
+    ip, idx = _t(g["row_ptr"]), _t(g["col_ind"])
+    cp, ri, pm = _t(g["col_ptr"]), _t(g["row_ind"]), _t(g["val_idx"])
+    slope = float(g["negative_slope"])
+    ar, ac, X = (_t(g[k]).requires_grad_(True) for k in ("attn_row", "attn_col", "V"))
+    dO = _t(g["dO"])
+    torch.manual_seed(seed)
+    out, emax, esum, mask = gat.gat_forward(ar.detach(), ac.detach(), ip, idx, slope, X.detach(), attn_drop)
+    assert tuple(mask.shape) == (len(g["col_ind"]), X.shape[1])
+    mask_np = mask.cpu().numpy() if attn_drop > 0 else None
+    args = (g["row_ptr"], g["col_ind"], g["attn_row"], g["attn_col"], slope, g["V"])
+    w_out, w_max, w_sum = oracle_mod.gat_train_forward(*args, mask_np, attn_drop)
+    w_gf, w_gr, w_gc = oracle_mod.gat_backward(*args, g["dO"], mask_np, attn_drop)
+    errs = dict(out=_close(out, w_out, "gat_forward out"), sum=_close(esum, w_sum, "edge_sum"))
+    deg = np.diff(g["row_ptr"])
+    _close(emax[torch.from_numpy(deg > 0).to(DEV)], w_max[deg > 0], "edge_max")
+    assert bool((emax[torch.from_numpy(deg == 0).to(DEV)] < -9e37).all())
+    gf, gr, gc = gat.gat_backward(slope, attn_drop, ip, idx, cp, ri, pm, emax, esum, mask, X.detach(), ar.detach(),
+                                  ac.detach(), dO)
+    errs.update(grad_feat=_close(gf, w_gf, "grad_feat"), grad_row=_close(gr, w_gr, "grad_attn_row"),
+                grad_col=_close(gc, w_gc, "grad_attn_col"))
+    # and through the autograd.Function, same seed -> same randoms
+    torch.manual_seed(seed)
+    o2 = GATConvFuse(ar, ac, ip, idx, cp, ri, pm, slope, X, attn_drop)
+    o2.backward(dO)
+    assert torch.equal(o2.detach(), out)
+    assert torch.equal(X.grad, gf) and torch.equal(ar.grad, gr) and torch.equal(ac.grad, gc)
+    return errs
+
+
+def test_gat_train_golden(oracle_mod, golden, golden_gat_train):
+    """Committed fixtures (no dropout: the binding draws its own randoms, so the *_drop expectations are checked
+    through the C ABI with the fixture's mask below)."""
+    import dfgnn_native as n
+    for name, t in golden_gat_train.items():
+        g = golden[name]
+        errs = _gat_train_case(oracle_mod, g, 0.0)
+        ip, idx = _t(g["row_ptr"]), _t(g["col_ind"])
+        cp, ri, pm = _t(g["col_ptr"]), _t(g["row_ind"]), _t(g["val_idx"])
+        ar, ac, X, dO, mask = _t(g["attn_row"]), _t(g["attn_col"]), _t(g["V"]), _t(g["dO"]), _t(t["edge_mask"])
+        m, h, f = X.shape
+        nnz, drop, slope = idx.numel(), float(t["attn_drop"]), float(g["negative_slope"])
+        out, gf = torch.empty_like(X), torch.empty_like(X)
+        emax, esum, gr, gc = (torch.empty(m, h, device=DEV) for _ in range(4))
+        ws = torch.empty(h, nnz, device=DEV)
+        st = torch.cuda.current_stream().cuda_stream
+        p = lambda x: x.data_ptr()  # noqa: E731
+        n.check(n.lib().dfgnn_gat_fwd_train(m, nnz, h, f, p(ip), p(idx), p(ar), p(ac), slope, p(X), p(mask), drop,
+                                            p(emax), p(esum), p(out), st), "fwd")
+        n.check(n.lib().dfgnn_gat_bwd(m, nnz, h, f, p(ip), p(idx), p(cp), p(ri), p(pm), p(ar), p(ac), slope, p(X),
+                                      p(emax), p(esum), p(mask), drop, p(dO), p(ws), p(gf), p(gr), p(gc), st), "bwd")
+        for got, key in ((out, "out"), (esum, "edge_sum"), (gf, "grad_feat"), (gr, "grad_attn_row"),
+                         (gc, "grad_attn_col")):
+            errs[key + "_drop"] = _close(got, t[key + "_drop"], f"{name}:{key}_drop")
+        print(name, {k: f"{v:.1e}" for k, v in errs.items()})
+    _loaded_native()
+
+
+@pytest.mark.parametrize("m,avg,h,f,kw", [
+    (1, 0, 1, 4, {}),
+    (5, 0, 2, 8, {}),
+    (333, 9, 1, 128, dict(empty_frac=0.1)),
+    (257, 40, 1, 64, dict(dup_frac=0.3)),
+    (64, 4, 8, 16, dict(empty_frac=0.5)),
+    (100, 30, 4, 32, {}),
+    (40, 6, 2, 256, {}),
+    (24, 5, 1, 512, {}),
+    (50, 7, 2, 7, {}),
+    (30, 6, 2, 130, {}),
+    (300, 12, 1, 128, dict(max_deg=5000)),
+    (40, 300, 1, 32, {}),
+])
+@pytest.mark.parametrize("attn_drop", [0.0, 0.3])
+def test_gat_train_random_graphs(oracle_mod, m, avg, h, f, kw, attn_drop):
+    g = _random_case(oracle_mod, 11 * m + f, m, avg, h, f, **kw)
+    print(_gat_train_case(oracle_mod, g, attn_drop, seed=m))
+
+
+def test_gat_train_pattern_like_batch(oracle_mod):
+    """The C3 shape (PATTERN-like batch, f = 128) at 64 graphs, through preprocess_Hyper_fw_bw's CSC arrays."""
+    from DFGNN.layers import preprocess_Hyper_fw_bw
+    from DFGNN.utils import synthetic as S
+    g = S.pattern_like(batch_size=64, seed=1).to(DEV)
+    A, rows, row_ptr, col_ind, val, col_ptr, row_ind, val_idx, smem = preprocess_Hyper_fw_bw(g)
+    m = g.num_nodes()
+    ar, ac, X = S.gat_features(m, 1, 128, seed=4, device=DEV)
+    dO = torch.randn(m, 1, 128, generator=torch.Generator().manual_seed(2)).to(DEV)
+    n_ = lambda t: t.cpu().numpy()  # noqa: E731
+    case = dict(row_ptr=n_(row_ptr), col_ind=n_(col_ind), col_ptr=n_(col_ptr), row_ind=n_(row_ind),
+                val_idx=n_(val_idx), attn_row=n_(ar), attn_col=n_(ac), V=n_(X), dO=n_(dO),
+                negative_slope=np.float32(0.2))
+    for drop in (0.0, 0.5):
+        print(drop, _gat_train_case(oracle_mod, case, drop))

@@ -75,8 +75,13 @@ def test_binding_rejects_cpu_tensors_and_bad_dtypes():
         fused_gtconv.gt_tiling_inference(ip, idx, val, 128, q, q, q)
     with pytest.raises(RuntimeError, match="must be on CUDA"):
         fused_gatconv.gat_inference_tiling(torch.ones(1, 1), torch.ones(1, 1), ip, idx, 0.2, q)
+    a = torch.ones(1, 1)
+    with pytest.raises(RuntimeError, match="must be on CUDA"):       # training pair: no CPU fallback either
+        fused_gatconv.gat_forward(a, a, ip, idx, 0.2, q, 0.0)
+    with pytest.raises(RuntimeError, match="must be on CUDA"):
+        fused_gatconv.gat_backward(0.2, 0.0, ip, idx, ip, idx, idx, a, a, a, q, a, a, q)
     with pytest.raises(NotImplementedError):
-        fused_gatconv.gat_forward(None, None, None, None, 0.2, None, 0.0)
+        fused_gatconv.gat_inference_hyper_v2(1024, a, a, ip, idx, 0.2, q)
 
 
 def _args(conv, fmt, dim, heads):

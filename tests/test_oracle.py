@@ -75,6 +75,79 @@ def test_known_answers(oracle_mod):
     np.testing.assert_allclose(gat[0, 0, 0], p[0] * 4 + p[1] * 8, rtol=1e-6)
 
 
+def test_gat_train_oracle_matches_golden(oracle_mod, golden, golden_gat_train):
+    for name, t in golden_gat_train.items():
+        g = golden[name]
+        args = (g["row_ptr"], g["col_ind"], g["attn_row"], g["attn_col"], float(g["negative_slope"]), g["V"])
+        for sfx, mask, drop in (("", None, 0.0), ("_drop", t["edge_mask"], float(t["attn_drop"]))):
+            out, emax, esum = oracle_mod.gat_train_forward(*args, mask, drop)
+            gf, gr, gc = oracle_mod.gat_backward(*args, g["dO"], mask, drop)
+            for got, key in ((out, "out"), (emax, "edge_max"), (esum, "edge_sum"), (gf, "grad_feat"),
+                             (gr, "grad_attn_row"), (gc, "grad_attn_col")):
+                np.testing.assert_allclose(got, t[key + sfx], rtol=2e-6, atol=4e-6, err_msg=f"{name}:{key}{sfx}")
+
+
+@pytest.mark.parametrize("m,avg,h,f,kw", [
+    (1, 0, 1, 4, {}),
+    (40, 3, 2, 16, dict(empty_frac=0.3)),
+    (64, 12, 2, 32, dict(dup_frac=0.2)),
+    (50, 5, 1, 128, dict(max_deg=300)),
+    (30, 4, 3, 7, {}),
+])
+def test_gat_train_oracle_vs_autograd(oracle_mod, m, avg, h, f, kw):
+    """GAT training pair: hand-derived gradients of oracle.c vs autograd of the edge-list
+    restatement, with and without attention dropout (same uniform randoms on both sides)."""
+    rng = np.random.default_rng(m * 77 + f)
+    indptr, indices, _ = random_graph(rng, m, avg, **kw)
+    ar, ac = (rng.standard_normal((m, h)).astype(np.float32) for _ in range(2))
+    X, dO = (rng.standard_normal((m, h, f)).astype(np.float32) for _ in range(2))
+    for mask, drop in ((None, 0.0), (rng.random((len(indices), h)).astype(np.float32), 0.4)):
+        out, emax, esum = oracle_mod.gat_train_forward(indptr, indices, ar, ac, 0.2, X, mask, drop)
+        gf, gr, gc = oracle_mod.gat_backward(indptr, indices, ar, ac, 0.2, X, dO, mask, drop)
+        o2, gf2, gr2, gc2 = torch_ref.gat_train(indptr, indices, ar, ac, 0.2, X, dO, mask, drop)
+        for a, b in ((out, o2), (gf, gf2), (gr, gr2), (gc, gc2)):
+            np.testing.assert_allclose(a, b.numpy(), rtol=0, atol=1e-9)
+        if mask is None:
+            np.testing.assert_allclose(out, oracle_mod.gat_forward(indptr, indices, ar, ac, 0.2, X), atol=1e-12)
+        deg = np.diff(indptr)
+        assert np.all(emax[deg == 0] < -9e37)                       # the reference's -1e38 sentinel
+        assert np.all(esum[deg == 0] == 0) and np.all(esum[deg > 0] >= 1.0)
+        # softmax gradients sum to zero over a row before the LeakyReLU factor: with slope == 1 grad_attn_row == 0
+        _, gr1, gc1 = oracle_mod.gat_backward(indptr, indices, ar, ac, 1.0, X, dO, mask, drop)
+        np.testing.assert_allclose(gr1, 0.0, atol=1e-10)
+
+
+def test_gat_train_known_answer(oracle_mod):
+    """One row, two neighbours, slope 0.2: pre = (-1, +1) -> s = (-0.2, 1); P = softmax(s);
+    dP = dO * X_j; G = P (dP - <P, dP>) * (0.2, 1)."""
+    indptr = np.array([0, 2, 2], np.int32)
+    indices = np.array([0, 1], np.int32)
+    ar = np.array([[0.0], [0.0]], np.float32)
+    ac = np.array([[-1.0], [1.0]], np.float32)
+    X = np.array([[[4.0]], [[8.0]]], np.float32)
+    dO = np.array([[[0.5]], [[7.0]]], np.float32)
+    p = np.exp([-0.2, 1.0]) / np.exp([-0.2, 1.0]).sum()
+    out, emax, esum = oracle_mod.gat_train_forward(indptr, indices, ar, ac, 0.2, X)
+    np.testing.assert_allclose(out[:, 0, 0], [p[0] * 4 + p[1] * 8, 0.0], rtol=1e-7)
+    np.testing.assert_allclose(emax[0, 0], 1.0)
+    np.testing.assert_allclose(esum[0, 0], 1.0 + np.exp(-1.2), rtol=1e-7)
+    gf, gr, gc = oracle_mod.gat_backward(indptr, indices, ar, ac, 0.2, X, dO)
+    dP = 0.5 * np.array([4.0, 8.0])
+    G = p * (dP - (p * dP).sum()) * np.array([0.2, 1.0])
+    np.testing.assert_allclose(gc[:, 0], G, rtol=1e-7)
+    np.testing.assert_allclose(gr[:, 0], [G.sum(), 0.0], rtol=1e-7, atol=1e-15)
+    np.testing.assert_allclose(gf[:, 0, 0], p * 0.5, rtol=1e-7)
+    # dropout: edge 0 dropped at attn_drop 0.5 -> out = 2 p1 X1; grad_feat[0] = 0; g = (0, 2 dP1)
+    mask = np.array([[0.1], [0.9]], np.float32)
+    out, _, _ = oracle_mod.gat_train_forward(indptr, indices, ar, ac, 0.2, X, mask, 0.5)
+    np.testing.assert_allclose(out[0, 0, 0], 2 * p[1] * 8, rtol=1e-7)
+    gf, gr, gc = oracle_mod.gat_backward(indptr, indices, ar, ac, 0.2, X, dO, mask, 0.5)
+    g = np.array([0.0, 2 * dP[1]])
+    G = p * (g - (p * g).sum()) * np.array([0.2, 1.0])
+    np.testing.assert_allclose(gc[:, 0], G, rtol=1e-7)
+    np.testing.assert_allclose(gf[:, 0, 0], [0.0, 2 * p[1] * 0.5], rtol=1e-7)
+
+
 def test_softmax_invariants(oracle_mod):
     """Properties the domain offers: rows of P sum to 1 (or 0 when empty); permuting a row's edges
     permutes P and leaves out unchanged; sum_i dV equals column sums of P weighted dO."""

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Profiling helper: run one hot-path entry point a few times on the C3 workload (for rocprofv3).
-usage: python3 tools/run_kernel.py [fwd|bwd|fwd_infer|gat] [iters] [batch_size]"""
+usage: python3 tools/run_kernel.py [fwd|bwd|fwd_infer|gat|gat_train|gat_train_drop] [iters] [batch_size]"""
 import os
 import sys
 
@@ -32,6 +32,16 @@ if what == "gat":
         gat.gat_inference_hyper(smem, ar, ac, row_ptr, col_ind, rows, 0.2, X)
     torch.cuda.synchronize()
     print("done gat", iters, m, g.num_edges())
+    sys.exit(0)
+if what.startswith("gat_train"):
+    import fused_gatconv as gat
+    ar, ac, X = S.gat_features(m, 1, 128, seed=6, device=dev)
+    drop = 0.5 if what.endswith("drop") else 0.0
+    for _ in range(iters):
+        out, emax, esum, mask = gat.gat_forward(ar, ac, row_ptr, col_ind, 0.2, X, drop)
+        gat.gat_backward(0.2, drop, row_ptr, col_ind, col_ptr, row_ind, val_idx, emax, esum, mask, X, ar, ac, dO)
+    torch.cuda.synchronize()
+    print("done", what, iters, m, g.num_edges())
     sys.exit(0)
 for _ in range(iters):
     if what == "fwd_infer":
