@@ -129,3 +129,18 @@ def get_plan(indptr, indices, f, enable=True):
     if plan.num_fit == 0:
         return None, None, False
     return plan.ptrs() + (plan.num_edge_global > 0,)
+
+
+def get_rows(row_ptr, nnz):
+    """Sorted COO row ids of a CSR structure (the COO half of the 'hyper' format), derived once per row_ptr tensor and
+    cached on it like the plan.  The reference's gat_forward / gat_backward take CSR only
+    (DFGNN/src/fused_gatconv/fused_gatconv.cpp:11-14, 291-300); the matrix-core kernels walk the edges by (row, col)
+    pairs, so the binding derives the row ids next to the plan -- preprocessing, once per batch structure."""
+    cached = row_ptr.__dict__.get("_dfgnn_rows")
+    if cached is None or cached[0] != (row_ptr._version, nnz):
+        deg = (row_ptr[1:] - row_ptr[:-1]).long()
+        rows = torch.repeat_interleave(torch.arange(deg.numel(), dtype=torch.int32, device=row_ptr.device), deg,
+                                       output_size=nnz)
+        cached = ((row_ptr._version, nnz), rows)
+        row_ptr.__dict__["_dfgnn_rows"] = cached
+    return cached[1]

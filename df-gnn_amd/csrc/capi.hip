@@ -198,30 +198,50 @@ int dfgnn_gat_tiling_fwd(int m, int nnz, int h, int f, const int *row_ptr, const
   return launch_gat_tiling_fwd(g, attn_row, attn_col, negative_slope, X, out, as_stream(stream));
 }
 
-int dfgnn_gat_fwd_train(int m, int nnz, int h, int f, const int *row_ptr, const int *col_ind,
+// The GAT training pair takes the matrix-core kernels when every range of the plan is dense and nothing is dropped.
+static bool gat_train_dense(Plan &p, const int *rows, const float *edge_mask, const int *plan, const int *plan_meta,
+                            int m, int nnz, int f, bool v4) {
+  if (!rows || edge_mask || !v4 || !dense_enabled()) return false;
+  if (f != 32 && f != 64 && f != 128) return false;
+  if (!make_plan(p, plan, plan_meta, m, nnz, f)) return false;
+  return p.num_dense > 0 && p.num_dense == p.num_fit && p.num_spill == 0;
+}
+
+int dfgnn_gat_fwd_train(int m, int nnz, int h, int f, const int *row_ptr, const int *col_ind, const int *rows,
                         const float *attn_row, const float *attn_col, float negative_slope, const float *X,
                         const float *edge_mask, float attn_drop, float *edge_max, float *edge_sum, float *out,
-                        dfgnn_stream_t stream) {
+                        const int *plan, const int *plan_meta, dfgnn_stream_t stream) {
   if (int c = check_common(m, nnz, h, f, row_ptr, col_ind)) return c < 0 ? c : 0;
   if (!attn_row || !attn_col || !X || !out || !edge_max || !edge_sum) return kErrBadArg;
   if (edge_mask && !(attn_drop >= 0.f && attn_drop < 1.f)) return kErrBadArg;
-  const Csr g{m, nnz, h, f, row_ptr, col_ind, nullptr, nullptr};
+  const Csr g{m, nnz, h, f, row_ptr, col_ind, rows, nullptr};
+  Plan p;
+  const bool v4 = (f % 4 == 0) && aligned16(X) && aligned16(out);
+  if (gat_train_dense(p, rows, edge_mask, plan, plan_meta, m, nnz, f, v4))
+    return launch_gat_dense_fwd(g, p, attn_row, attn_col, negative_slope, X, out, as_stream(stream), edge_max,
+                                edge_sum);
   return launch_gat_train_fwd(g, attn_row, attn_col, negative_slope, X, edge_mask, attn_drop, edge_max, edge_sum,
                               out, as_stream(stream));
 }
 
-int dfgnn_gat_bwd(int m, int nnz, int h, int f, const int *row_ptr, const int *col_ind, const int *col_ptr,
-                  const int *row_ind, const int *permute, const float *attn_row, const float *attn_col,
-                  float negative_slope, const float *X, const float *edge_max, const float *edge_sum,
-                  const float *edge_mask, float attn_drop, const float *grad_out, float *grad_edge,
-                  float *grad_feat, float *grad_attn_row, float *grad_attn_col, dfgnn_stream_t stream) {
+int dfgnn_gat_bwd(int m, int nnz, int h, int f, const int *row_ptr, const int *col_ind, const int *rows,
+                  const int *col_ptr, const int *row_ind, const int *permute, const float *attn_row,
+                  const float *attn_col, float negative_slope, const float *X, const float *edge_max,
+                  const float *edge_sum, const float *edge_mask, float attn_drop, const float *grad_out,
+                  float *grad_edge, float *grad_feat, float *grad_attn_row, float *grad_attn_col, const int *plan,
+                  const int *plan_meta, dfgnn_stream_t stream) {
   if (int c = check_common(m, nnz, h, f, row_ptr, col_ind)) return c < 0 ? c : 0;
   if (!attn_row || !attn_col || !X || !edge_max || !edge_sum || !grad_out || !grad_feat || !grad_attn_row ||
-      !grad_attn_col || !col_ptr)
+      !grad_attn_col)
     return kErrBadArg;
-  if (nnz > 0 && (!row_ind || !permute || !grad_edge)) return kErrBadArg;
   if (edge_mask && !(attn_drop >= 0.f && attn_drop < 1.f)) return kErrBadArg;
-  const Csr g{m, nnz, h, f, row_ptr, col_ind, nullptr, nullptr};
+  const Csr g{m, nnz, h, f, row_ptr, col_ind, rows, nullptr};
+  Plan p;
+  const bool v4 = (f % 4 == 0) && aligned16(X) && aligned16(grad_out) && aligned16(grad_feat);
+  if (gat_train_dense(p, rows, edge_mask, plan, plan_meta, m, nnz, f, v4))
+    return launch_gat_dense_bwd(g, p, attn_row, attn_col, negative_slope, X, edge_max, edge_sum, grad_out, grad_feat,
+                                grad_attn_row, grad_attn_col, as_stream(stream));
+  if (!col_ptr || (nnz > 0 && (!row_ind || !permute || !grad_edge))) return kErrBadArg;
   if (int rc = launch_gat_bwd_rows(g, attn_row, attn_col, negative_slope, X, edge_max, edge_sum, edge_mask,
                                    attn_drop, grad_out, grad_edge, grad_attn_row, as_stream(stream)))
     return rc;

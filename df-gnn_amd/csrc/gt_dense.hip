@@ -49,7 +49,9 @@ template <int F, bool WRITE_ATTN, int NS, int CR, int NCH, bool GAT = false>
 __device__ __forceinline__ void dense_fwd_body(float *lds, int lds_bytes, const Csr &g, int n0, int n, int e0, int ne,
                                                int head, const float *__restrict__ Q, const float *__restrict__ K,
                                                const float *__restrict__ V, float *__restrict__ attn_edge,
-                                               float *__restrict__ out, float slope = 0.f) {
+                                               float *__restrict__ out, float slope = 0.f,
+                                               float *__restrict__ stat_max = nullptr,
+                                               float *__restrict__ stat_sum = nullptr) {
   using D = DenseCfg<F>;
   constexpr int RS = D::RS, KT = D::KT, FT = D::FT, TPC = CR / 16, NT = TPC * NCH;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
@@ -232,6 +234,12 @@ __device__ __forceinline__ void dense_fwd_body(float *lds, int lds_bytes, const 
         }
       sum = xor16_32_sum(sum);
       inv[s] = (sum != 0.f) ? 1.f / sum : 0.f;
+      if constexpr (GAT) {  // training forward: the row statistics the backward recomputes P from
+        if (stat_max && i < n && L.mq == 0) {
+          stat_max[(size_t)(n0 + i) * g.h + head] = (mx == -INFINITY) ? -1e38f : mx;
+          stat_sum[(size_t)(n0 + i) * g.h + head] = sum;
+        }
+      }
       if constexpr (WRITE_ATTN) {
         // attn_edge (CSR order): through LDS when the range's edge array fits (then the strip streams its own
         // contiguous slice out), else straight from the registers (scattered 4-byte stores)
@@ -330,19 +338,21 @@ __global__ __launch_bounds__(kDenseThreads) void gat_dense_fwd_kernel(Csr g, con
                                                                       const float *__restrict__ attn_row,
                                                                       const float *__restrict__ attn_col, float slope,
                                                                       const float *__restrict__ X,
-                                                                      float *__restrict__ out, int lds_bytes) {
+                                                                      float *__restrict__ out, int lds_bytes,
+                                                                      float *__restrict__ edge_max,
+                                                                      float *__restrict__ edge_sum) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int n0 = fit[2 * blockIdx.x], n1 = fit[2 * blockIdx.x + 1] & kPlanRangeMask;
   const int n = n1 - n0, e0 = g.row_ptr[n0], ne = g.row_ptr[n1] - e0;
   if (n <= kDenseChunkRows)
     dense_fwd_body<F, false, 1, kDenseChunkRows, 1, true>(lds, lds_bytes, g, n0, n, e0, ne, blockIdx.y, attn_row, attn_col, X,
-                                                          nullptr, out, slope);
+                                                          nullptr, out, slope, edge_max, edge_sum);
   else if (n <= kDenseWideRows)
     dense_fwd_body<F, false, 2, kDenseWideRows, 1, true>(lds, lds_bytes, g, n0, n, e0, ne, blockIdx.y, attn_row, attn_col, X,
-                                                         nullptr, out, slope);
+                                                         nullptr, out, slope, edge_max, edge_sum);
   else
     dense_fwd_body<F, false, 2, kDenseChunkRows, 2, true>(lds, lds_bytes, g, n0, n, e0, ne, blockIdx.y, attn_row, attn_col, X,
-                                                          nullptr, out, slope);
+                                                          nullptr, out, slope, edge_max, edge_sum);
 }
 
 // =====================================================================================================================
@@ -361,12 +371,24 @@ struct DenseBwdGeom {
   static constexpr int TS = CW + 8;                            // floats per tile row == 2 x TS bf16 (hi | lo)
 };
 
-template <int F, int CW, int NBLK>
+// GAT training backward (GAT = true; Q = attn_row [m, h], K = attn_col [m, h], V = X, dV = grad_feat; attn_edge, dQ, dK
+// unused): P is recomputed per edge from the row statistics of the forward (staged in LDS next to the tile), the two
+// feature products are the GT ones (grad_feat^T = dO^T P, dP^T = X dO^T), and instead of the dQ / dK products
+// G = dS LeakyReLU'(attn_row[i] + attn_col[j]) is summed over rows (registers) and columns (per-strip partial sums
+// through the tile, which is free by then; fixed summation order, no atomics).
+struct GatBwdArgs {
+  const float *edge_max, *edge_sum;  // [m, h] from the training forward
+  float slope;
+  float *grad_row, *grad_col;        // [m, h]
+};
+
+template <int F, int CW, int NBLK, bool GAT = false>
 __device__ __forceinline__ void dense_bwd_body(float *lds, const Csr &g, int n0, int n, int e0, int ne, int head,
                                                const float *__restrict__ Q, const float *__restrict__ K,
                                                const float *__restrict__ V, const float *__restrict__ attn_edge,
                                                const float *__restrict__ dO, float *__restrict__ dQ,
-                                               float *__restrict__ dK, float *__restrict__ dV) {
+                                               float *__restrict__ dK, float *__restrict__ dV,
+                                               const GatBwdArgs ga = GatBwdArgs{}) {
   using D = DenseCfg<F>;
   using G = DenseBwdGeom<CW, NBLK>;
   constexpr int RS = D::RS, KT = D::KT, FT = D::FT, RB = G::RB, RBP = G::RBP, U = G::U, TS = G::TS;
@@ -381,8 +403,24 @@ __device__ __forceinline__ void dense_bwd_body(float *lds, const Csr &g, int n0,
               *dOb = dO + (size_t)n0 * hf + hoff;
   float *dQb = dQ + (size_t)n0 * hf + hoff, *dKb = dK + (size_t)n0 * hf + hoff, *dVb = dV + (size_t)n0 * hf + hoff;
   const float *attn_h = attn_edge + (size_t)head * g.nnz;
+  // GAT: per-node scalars of the range, [SN] each, behind the tile: attn_row, attn_col, edge_max, 1 / edge_sum
+  constexpr int SN = NBLK * CW;
+  float *arl = T + RBP * TS, *acl = arl + SN, *mxl = acl + SN, *ivl = mxl + SN;
+  (void)arl, (void)acl, (void)mxl, (void)ivl;
 
   DFGNN_DSTAMP(0)
+  if constexpr (GAT) {
+    const int tid = opaque_tid();
+    if (tid < SN) {
+      const size_t k = (size_t)(n0 + min(tid, n - 1)) * g.h + head;
+      const float a = Q[k], c = K[k], mx = ga.edge_max[k], sm = ga.edge_sum[k];
+      const bool valid = tid < n;
+      arl[tid] = valid ? a : 0.f;
+      acl[tid] = valid ? c : 0.f;
+      mxl[tid] = valid ? mx : 0.f;
+      ivl[tid] = (valid && sm != 0.f) ? 1.f / sm : 0.f;
+    }  // (visible to the first scatter: load_tile has a barrier between zeroing the tile and scattering)
+  }
   // The image that is needed next is fetched one phase ahead into registers (`st`) -- for a single column block; with
   // two column blocks the registers hold dP / P / dS of both and the image is fetched where it is stored.
   DenseStageRegs<F, CW> st;
@@ -415,8 +453,12 @@ __device__ __forceinline__ void dense_bwd_body(float *lds, const Csr &g, int n0,
       const int ea0 = min(ea, g.nnz - 1);
       pi[k] = ld32(g.rows + ea0, e);
       pj[k] = ld32(g.col_ind + ea0, e);
-      pa[k] = ld32(attn_h + ea0, e);
+      if constexpr (!GAT) pa[k] = ld32(attn_h + ea0, e);
     }
+  };
+  // GAT: P of edge (row i, column j of the range) from the staged scalars
+  auto gat_p = [&](int i, int j) {
+    return fast_exp(leaky_relu(arl[i] + acl[j], ga.slope) - mxl[i]) * ivl[i];
   };
   // Zero the tile, scatter P of tile (i0, j0) into it (fp32; edges [ea, eb) are the rows of the row block) and, if
   // `commit`, put the prefetched image into LDS.  `prefetched`: the first PRE edges per thread are in (pi, pj, pa).
@@ -429,7 +471,10 @@ __device__ __forceinline__ void dense_bwd_body(float *lds, const Csr &g, int n0,
 #pragma unroll
       for (int k = 0; k < PRE; ++k) {
         const int j = pj[k] - n0 - j0;
-        if (tid + k * kDenseThreads < eb - ea && j >= 0 && j < CW) T[(pi[k] - n0 - i0) * TS + j] = pa[k];
+        if (tid + k * kDenseThreads < eb - ea && j >= 0 && j < CW) {
+          if constexpr (GAT) T[(pi[k] - n0 - i0) * TS + j] = gat_p(pi[k] - n0, pj[k] - n0);
+          else T[(pi[k] - n0 - i0) * TS + j] = pa[k];
+        }
       }
     }
     constexpr int B = 8;
@@ -441,12 +486,15 @@ __device__ __forceinline__ void dense_bwd_body(float *lds, const Csr &g, int n0,
         const unsigned e = (unsigned)min(base + tid + k * kDenseThreads, eb - ea - 1);  // (eb > ea inside this loop)
         bi[k] = ld32(g.rows + ea, e);
         bj[k] = ld32(g.col_ind + ea, e);
-        ba[k] = ld32(attn_h + ea, e);
+        if constexpr (!GAT) ba[k] = ld32(attn_h + ea, e);
       }
 #pragma unroll
       for (int k = 0; k < B; ++k) {
         const int j = bj[k] - n0 - j0;
-        if (base + tid + k * kDenseThreads < eb - ea && j >= 0 && j < CW) T[(bi[k] - n0 - i0) * TS + j] = ba[k];
+        if (base + tid + k * kDenseThreads < eb - ea && j >= 0 && j < CW) {
+          if constexpr (GAT) T[(bi[k] - n0 - i0) * TS + j] = gat_p(bi[k] - n0, bj[k] - n0);
+          else T[(bi[k] - n0 - i0) * TS + j] = ba[k];
+        }
       }
     }
     if (commit) image_commit();  // after the scatter: the edge loads were issued before the image's
@@ -521,6 +569,7 @@ __device__ __forceinline__ void dense_bwd_body(float *lds, const Csr &g, int n0,
   int ea = e0, eb = (RB < n) ? g.row_ptr[n0 + RB] : e0 + ne;  // edges of the current row block
   edges_prefetch(ea, eb);
   image_prefetch(dOb, 0, min(n, RB));
+  float gcol = 0.f;  // GAT: grad_attn_col of column opaque_tid(), accumulated over the row blocks
   for (int i0 = 0; i0 < n; i0 += RB) {
     const int ni = min(n - i0, RB);
     const bool row_wave = wave * 16 < ni;
@@ -576,8 +625,17 @@ __device__ __forceinline__ void dense_bwd_body(float *lds, const Csr &g, int n0,
 #pragma unroll
     for (int jc = 0; jc < NBLK; ++jc) {
       image_commit();  // V rows of column block jc
-      if (jc + 1 < NBLK) image_prefetch(Vb, (jc + 1) * CW, n);
-      else image_prefetch(Kb, 0, n);  // next image: K rows 0..
+      if (jc + 1 < NBLK) {
+        image_prefetch(Vb, (jc + 1) * CW, n);
+      } else if constexpr (!GAT) {
+        image_prefetch(Kb, 0, n);  // next image: K rows 0..
+      } else if constexpr (CW * NBLK > RB) {
+        // GAT: the next row block's dO rows are all that is left to fetch (its edges are fetched after dS: they would
+        // not fit next to dP / P).  Unconditional -- the last row block re-reads its own rows (L2 hits, unused): a
+        // prefetch under a condition turns the staging registers into loop-carried values and spills them.
+        const bool more = i0 + RB < n;
+        image_prefetch(dOb, more ? i0 + RB : i0, more ? min(n, i0 + 2 * RB) : i0 + ni);
+      }
       lds_barrier();
       if (row_wave) {
         const LaneIds L = lane_ids();
@@ -613,6 +671,48 @@ __device__ __forceinline__ void dense_bwd_body(float *lds, const Csr &g, int n0,
           for (int r = 0; r < 4; ++r) dS[jc][u][r] = Pr[jc][u][r] * (dS[jc][u][r] - t);
     }
     DFGNN_DSTAMP(2)
+
+    if constexpr (GAT) {
+      // ---- G = dS LeakyReLU'(pre): row sums -> grad_attn_row, per-strip column sums -> the tile -> grad_attn_col -------
+      float *cpart = T;  // [kDenseWaves][SN]
+      if (i0 + RB < n) {
+        ea = eb;
+        eb = (i0 + 2 * RB < n) ? g.row_ptr[n0 + i0 + 2 * RB] : e0 + ne;
+      }
+      if (row_wave) {
+        const LaneIds L = lane_ids();
+        const int i = i0 + wave * 16 + L.mi;
+        const float ari = arl[min(i, n - 1)];
+        float rs = 0.f;
+#pragma unroll
+        for (int jc = 0; jc < NBLK; ++jc)
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            const float4 a = *reinterpret_cast<const float4 *>(acl + jc * CW + 16 * u + 4 * L.mq);
+            const float av[4] = {a.x, a.y, a.z, a.w};
+            float cs[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float ge = dS[jc][u][r] * ((ari + av[r] > 0.f) ? 1.f : ga.slope);
+              rs += ge;
+              cs[r] = lanes_sum<16>(ge);  // over the strip's 16 rows (the 16 lanes of a DPP row share mq)
+            }
+            if (L.mi == 0)
+              *reinterpret_cast<float4 *>(cpart + wave * SN + jc * CW + 16 * u + 4 * L.mq) = make_float4(cs[0], cs[1], cs[2], cs[3]);
+          }
+        rs = xor16_32_sum(rs);
+        if (L.mq == 0 && i < i0 + ni) ga.grad_row[(size_t)(n0 + i) * g.h + head] = rs;
+      }
+      lds_barrier();
+      {
+        const int tid = opaque_tid();
+        if (tid < SN)
+          for (int w = 0; w * 16 < ni; ++w) gcol += cpart[w * SN + tid];
+      }
+      if constexpr (NBLK == 1 && CW > RB) edges_prefetch(ea, eb);  // (clamped loads: harmless after the last block)
+      lds_barrier();  // the next row block zeroes the tile
+      continue;
+    }
 
     // ---- dQ^T = K^T dS^T (accumulated over the column blocks in registers) and dK^T = Q^T dS ---------------------------
     f32x4 qacc[FT];
@@ -661,6 +761,30 @@ __device__ __forceinline__ void dense_bwd_body(float *lds, const Csr &g, int n0,
     }
     DFGNN_DSTAMP(8)
   }
+  if constexpr (GAT) {
+    const int tid = opaque_tid();
+    if (tid < n) ga.grad_col[(size_t)(n0 + tid) * g.h + head] = gcol;
+  }
+}
+
+// GAT training backward over the dense ranges (no attention dropout): replaces mhspmm_backward_kernel + mhsddmm +
+// fused_backward_kernel (DFGNN/src/fused_gatconv/fused_gatconv_kernel.cu:609-865) for them.
+template <int F>
+__global__ __launch_bounds__(kDenseThreads) void gat_dense_bwd_kernel(
+    Csr g, const int *__restrict__ fit, const float *__restrict__ attn_row, const float *__restrict__ attn_col,
+    const float *__restrict__ X, const float *__restrict__ dO, float *__restrict__ grad_feat, GatBwdArgs ga) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int n0 = fit[2 * blockIdx.x], n1 = fit[2 * blockIdx.x + 1] & kPlanRangeMask;
+  const int n = n1 - n0, e0 = g.row_ptr[n0], ne = g.row_ptr[n1] - e0;
+  if (n <= kDenseChunkRows)
+    dense_bwd_body<F, kDenseChunkRows, 1, true>(lds, g, n0, n, e0, ne, blockIdx.y, attn_row, attn_col, X, nullptr, dO,
+                                                nullptr, nullptr, grad_feat, ga);
+  else if (n <= kDenseWideRows)
+    dense_bwd_body<F, kDenseWideRows, 1, true>(lds, g, n0, n, e0, ne, blockIdx.y, attn_row, attn_col, X, nullptr, dO,
+                                               nullptr, nullptr, grad_feat, ga);
+  else
+    dense_bwd_body<F, kDenseChunkRows, 2, true>(lds, g, n0, n, e0, ne, blockIdx.y, attn_row, attn_col, X, nullptr, dO,
+                                                nullptr, nullptr, grad_feat, ga);
 }
 
 template <int F>
@@ -717,13 +841,28 @@ int launch_gt_dense_fwd(const Csr &g, const Plan &p, const float *Q, const float
 }
 
 int launch_gat_dense_fwd(const Csr &g, const Plan &p, const float *attn_row, const float *attn_col, float slope,
-                         const float *X, float *out, hipStream_t s) {
+                         const float *X, float *out, hipStream_t s, float *edge_max, float *edge_sum) {
   if (p.num_dense == 0) return 0;
   const dim3 grid(p.num_dense, g.h);
   return dispatch_dense(g.f, [&](auto fc) {
     constexpr int F = decltype(fc)::value;
     if (int rc = set_max_lds(gat_dense_fwd_kernel<F>)) return rc;
-    gat_dense_fwd_kernel<F><<<grid, kDenseThreads, kLdsBytes, s>>>(g, p.fit(), attn_row, attn_col, slope, X, out, kLdsBytes);
+    gat_dense_fwd_kernel<F><<<grid, kDenseThreads, kLdsBytes, s>>>(g, p.fit(), attn_row, attn_col, slope, X, out, kLdsBytes,
+                                                                   edge_max, edge_sum);
+    return launch_status();
+  });
+}
+
+int launch_gat_dense_bwd(const Csr &g, const Plan &p, const float *attn_row, const float *attn_col, float slope,
+                         const float *X, const float *edge_max, const float *edge_sum, const float *grad_out,
+                         float *grad_feat, float *grad_row, float *grad_col, hipStream_t s) {
+  if (p.num_dense == 0) return 0;
+  const dim3 grid(p.num_dense, g.h);
+  const GatBwdArgs ga{edge_max, edge_sum, slope, grad_row, grad_col};
+  return dispatch_dense(g.f, [&](auto fc) {
+    constexpr int F = decltype(fc)::value;
+    if (int rc = set_max_lds(gat_dense_bwd_kernel<F>)) return rc;
+    gat_dense_bwd_kernel<F><<<grid, kDenseThreads, kLdsBytes, s>>>(g, p.fit(), attn_row, attn_col, X, grad_out, grad_feat, ga);
     return launch_status();
   });
 }

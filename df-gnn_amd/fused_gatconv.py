@@ -10,7 +10,7 @@ behind FusedGATFunction.  The experimental hyper_v2 / hyper_recompute / tb entry
 import torch
 
 import dfgnn_native as _n
-from _binding_util import check_contiguous, check_device, check_dtype, get_plan, ptr, stream_ptr
+from _binding_util import check_contiguous, check_device, check_dtype, get_plan, get_rows, ptr, stream_ptr
 
 # Set to False to force the general (plan-less) kernels; results are identical either way.
 USE_BLOCK_PLAN = True
@@ -108,6 +108,17 @@ def _next(name):
     return fn
 
 
+def _train_plan(row_ptr, col_ind, f, attn_drop):
+    """(rows, plan, meta) for the training pair: the block plan and the COO row ids when the batch qualifies for the
+    matrix-core kernels (no dropout; the library checks that every range of the plan is dense), else Nones."""
+    if attn_drop > 0.0:
+        return None, None, None
+    plan, meta, _ = get_plan(row_ptr, col_ind, f, USE_BLOCK_PLAN)
+    if plan is None:
+        return None, None, None
+    return get_rows(row_ptr, col_ind.size(0)), plan, meta
+
+
 def gat_forward(attn_row, attn_col, row_ptr, col_ind, negative_slope, in_feat, attn_drop):
     """fused_gatconv.cpp:11-32 -> [out_feat[m,h,f], edge_max[m,h], edge_sum[m,h], edge_mask[nnz,h]]
 
@@ -130,10 +141,11 @@ def gat_forward(attn_row, attn_col, row_ptr, col_ind, negative_slope, in_feat, a
         else:
             edge_mask = torch.ones((1, 1), dtype=torch.float32, device=dev).expand(nnz, h)
             mask_ptr = None
-        _n.check(_n.lib().dfgnn_gat_fwd_train(m, nnz, h, f, ptr(row_ptr), ptr(col_ind), ptr(attn_row),
+        rows, plan, meta = _train_plan(row_ptr, col_ind, f, attn_drop)
+        _n.check(_n.lib().dfgnn_gat_fwd_train(m, nnz, h, f, ptr(row_ptr), ptr(col_ind), ptr(rows), ptr(attn_row),
                                               ptr(attn_col), float(negative_slope), ptr(in_feat), mask_ptr,
-                                              attn_drop, ptr(edge_max), ptr(edge_sum), ptr(out), stream_ptr(dev)),
-                 "gat_forward")
+                                              attn_drop, ptr(edge_max), ptr(edge_sum), ptr(out), plan, meta,
+                                              stream_ptr(dev)), "gat_forward")
     return [out, edge_max, edge_sum, edge_mask]
 
 
@@ -168,11 +180,12 @@ def gat_backward(negative_slope, attn_drop, row_ptr, col_ind, col_ptr, row_ind, 
         grad_attn_row = torch.empty((m, h), dtype=torch.float32, device=dev)
         grad_attn_col = torch.empty((m, h), dtype=torch.float32, device=dev)
         grad_edge = torch.empty((h, nnz), dtype=torch.float32, device=dev)
-        _n.check(_n.lib().dfgnn_gat_bwd(m, nnz, h, f, ptr(row_ptr), ptr(col_ind), ptr(col_ptr), ptr(row_ind),
-                                        ptr(permute), ptr(attn_row), ptr(attn_col), float(negative_slope),
-                                        ptr(in_feat), ptr(edge_max), ptr(edge_sum), mask_ptr, attn_drop, ptr(grad),
-                                        ptr(grad_edge), ptr(grad_feat), ptr(grad_attn_row), ptr(grad_attn_col),
-                                        stream_ptr(dev)), "gat_backward")
+        rows, plan, meta = _train_plan(row_ptr, col_ind, f, attn_drop)
+        _n.check(_n.lib().dfgnn_gat_bwd(m, nnz, h, f, ptr(row_ptr), ptr(col_ind), ptr(rows), ptr(col_ptr),
+                                        ptr(row_ind), ptr(permute), ptr(attn_row), ptr(attn_col),
+                                        float(negative_slope), ptr(in_feat), ptr(edge_max), ptr(edge_sum), mask_ptr,
+                                        attn_drop, ptr(grad), ptr(grad_edge), ptr(grad_feat), ptr(grad_attn_row),
+                                        ptr(grad_attn_col), plan, meta, stream_ptr(dev)), "gat_backward")
     return [grad_feat, grad_attn_row, grad_attn_col]
 
 

@@ -156,24 +156,32 @@ int dfgnn_gat_tiling_fwd(int m, int nnz, int h, int f, const int *row_ptr, const
  *   fused_gatconv_kernel.cu:1074-1083; the binding draws it with torch.rand so runs are reproducible).
  *   Edge e of head hd is kept iff edge_mask[e*h + hd] > attn_drop and its attention is scaled by
  *   1 / (1 - attn_drop).  NULL = no dropout (attn_drop is then ignored); with a mask, 0 <= attn_drop < 1.
+ * rows / plan / plan_meta: optional (NULL = general CSR kernels).  With all three, no dropout, and a plan whose
+ *   ranges are all marked dense (meta[9] == meta[0], meta[1] == 0: a batch of small dense graphs), both calls
+ *   run on the matrix-core kernels (one workgroup per member graph, as dfgnn_gt_hyper_fwd / dfgnn_gt_bwd do).
+ *   The reference's gat_forward / gat_backward take no COO rows: the binding derives them from row_ptr once per
+ *   batch structure, next to the plan.
  *
  * dfgnn_gat_fwd_train replaces gat_forward (fused_gatconv.cpp:11-32, fused_gatconv_kernel.cu:24-125, 1062-1129):
- *   CSR only; writes out[m, h, f], edge_max, edge_sum. */
+ *   writes out[m, h, f], edge_max, edge_sum. */
 int dfgnn_gat_fwd_train(int m, int nnz, int h, int f, const int *row_ptr, const int *col_ind,
-                        const float *attn_row, const float *attn_col, float negative_slope,
-                        const float *X, const float *edge_mask, float attn_drop, float *edge_max,
-                        float *edge_sum, float *out, dfgnn_stream_t stream);
+                        const int *rows, const float *attn_row, const float *attn_col,
+                        float negative_slope, const float *X, const float *edge_mask, float attn_drop,
+                        float *edge_max, float *edge_sum, float *out, const int *plan,
+                        const int *plan_meta, dfgnn_stream_t stream);
 
 /* replaces gat_backward (fused_gatconv.cpp:291-353, fused_gatconv_kernel.cu:609-865, 1172-1244).
  * col_ptr int32[m+1], row_ind int32[nnz], permute int32[nnz] (CSR slot of each CSC entry; the GT path calls
- * it val_idx).  grad_edge: caller scratch fp32[h, nnz].  Writes grad_feat fp32[m, h, f], grad_attn_row and
- * grad_attn_col fp32[m, h] in full (no pre-zeroing, no atomics: the column sums are deterministic). */
+ * it val_idx).  grad_edge: caller scratch fp32[h, nnz] (untouched on the matrix-core path).  Writes grad_feat
+ * fp32[m, h, f], grad_attn_row and grad_attn_col fp32[m, h] in full (no pre-zeroing, no atomics: the column
+ * sums are deterministic). */
 int dfgnn_gat_bwd(int m, int nnz, int h, int f, const int *row_ptr, const int *col_ind,
-                  const int *col_ptr, const int *row_ind, const int *permute, const float *attn_row,
-                  const float *attn_col, float negative_slope, const float *X, const float *edge_max,
-                  const float *edge_sum, const float *edge_mask, float attn_drop,
-                  const float *grad_out, float *grad_edge, float *grad_feat, float *grad_attn_row,
-                  float *grad_attn_col, dfgnn_stream_t stream);
+                  const int *rows, const int *col_ptr, const int *row_ind, const int *permute,
+                  const float *attn_row, const float *attn_col, float negative_slope, const float *X,
+                  const float *edge_max, const float *edge_sum, const float *edge_mask,
+                  float attn_drop, const float *grad_out, float *grad_edge, float *grad_feat,
+                  float *grad_attn_row, float *grad_attn_col, const int *plan, const int *plan_meta,
+                  dfgnn_stream_t stream);
 
 #ifdef __cplusplus
 }

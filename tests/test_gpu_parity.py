@@ -560,10 +560,11 @@ def test_gat_train_golden(oracle_mod, golden, golden_gat_train):
         ws = torch.empty(h, nnz, device=DEV)
         st = torch.cuda.current_stream().cuda_stream
         p = lambda x: x.data_ptr()  # noqa: E731
-        n.check(n.lib().dfgnn_gat_fwd_train(m, nnz, h, f, p(ip), p(idx), p(ar), p(ac), slope, p(X), p(mask), drop,
-                                            p(emax), p(esum), p(out), st), "fwd")
-        n.check(n.lib().dfgnn_gat_bwd(m, nnz, h, f, p(ip), p(idx), p(cp), p(ri), p(pm), p(ar), p(ac), slope, p(X),
-                                      p(emax), p(esum), p(mask), drop, p(dO), p(ws), p(gf), p(gr), p(gc), st), "bwd")
+        n.check(n.lib().dfgnn_gat_fwd_train(m, nnz, h, f, p(ip), p(idx), None, p(ar), p(ac), slope, p(X), p(mask), drop,
+                                            p(emax), p(esum), p(out), None, None, st), "fwd")
+        n.check(n.lib().dfgnn_gat_bwd(m, nnz, h, f, p(ip), p(idx), None, p(cp), p(ri), p(pm), p(ar), p(ac), slope,
+                                      p(X), p(emax), p(esum), p(mask), drop, p(dO), p(ws), p(gf), p(gr), p(gc), None,
+                                      None, st), "bwd")
         for got, key in ((out, "out"), (esum, "edge_sum"), (gf, "grad_feat"), (gr, "grad_attn_row"),
                          (gc, "grad_attn_col")):
             errs[key + "_drop"] = _close(got, t[key + "_drop"], f"{name}:{key}_drop")
@@ -606,3 +607,74 @@ def test_gat_train_pattern_like_batch(oracle_mod):
                 negative_slope=np.float32(0.2))
     for drop in (0.0, 0.5):
         print(drop, _gat_train_case(oracle_mod, case, drop))
+
+
+@pytest.mark.parametrize("h,f", [(1, 128), (2, 64), (3, 32)])
+def test_gat_train_dense_every_geometry(oracle_mod, h, f):
+    """GAT training pair on the matrix-core kernels (gat_dense_fwd_kernel with row statistics, gat_dense_bwd_kernel): a
+    batch whose ranges are all dense and hit every geometry (1 strip, <= 128 nodes, 129-160 nodes with two row blocks,
+    161-255 nodes with 2 x 2 tiles, isolated nodes, a directed graph whose last rows have in-edges only), against
+    the oracle and against the general CSR kernels."""
+    import fused_gatconv as gat
+    from DFGNN.layers import preprocess_Hyper_fw_bw
+    from DFGNN.utils import Graph, batch
+    from DFGNN.utils import synthetic as S
+    rng = np.random.default_rng(23 + f)
+
+    def er(n, p, drop_rows=()):
+        iu, ju = np.triu_indices(n, k=1)
+        keep = rng.random(len(iu)) < p
+        keep &= ~np.isin(iu, drop_rows) & ~np.isin(ju, drop_rows)
+        return np.concatenate([iu[keep], ju[keep]]), np.concatenate([ju[keep], iu[keep]])
+
+    graphs = []
+    for n, p in ((9, 0.9), (17, 0.6), (64, 0.5), (128, 0.35), (129, 0.3), (145, 0.4), (160, 0.3), (161, 0.3), (200, 0.25),
+                 (255, 0.2)):
+        s_, d_ = er(n, p)
+        graphs.append(Graph(s_, d_, n))
+    s_, d_ = er(70, 0.5, drop_rows=(0, 33, 69))
+    graphs.append(Graph(s_, d_, 70))
+    keep = rng.random((80, 140)) < 0.3
+    ds_, dd_ = np.nonzero(keep)
+    graphs.append(Graph(ds_.astype(np.int64), dd_.astype(np.int64), 140))
+    g = batch(graphs).to(DEV)
+    A, rows, row_ptr, col_ind, val, col_ptr, row_ind, val_idx, smem = preprocess_Hyper_fw_bw(g)
+    m = g.num_nodes()
+    ar, ac, X = S.gat_features(m, h, f, seed=8, device=DEV)
+    dO = torch.randn(m, h, f, generator=torch.Generator().manual_seed(3)).to(DEV)
+    out, emax, esum, mask = gat.gat_forward(ar, ac, row_ptr, col_ind, 0.2, X, 0.0)
+    plan = row_ptr._dfgnn_plans[f]
+    assert plan.num_dense == plan.num_fit > 0 and plan.num_spill == 0      # -> the library takes the dense kernels
+    assert torch.equal(row_ptr._dfgnn_rows[1], rows)                        # derived COO rows == preprocess_Hyper's
+    gf, gr, gc = gat.gat_backward(0.2, 0.0, row_ptr, col_ind, col_ptr, row_ind, val_idx, emax, esum, mask, X, ar, ac, dO)
+    n_ = lambda t: t.cpu().numpy()  # noqa: E731
+    args = (n_(row_ptr), n_(col_ind), n_(ar), n_(ac), 0.2, n_(X))
+    w_out, w_max, w_sum = oracle_mod.gat_train_forward(*args)
+    w_gf, w_gr, w_gc = oracle_mod.gat_backward(*args, n_(dO))
+    deg = np.diff(n_(row_ptr))
+    has = torch.from_numpy(deg > 0).to(DEV)
+    errs = dict(out=_close(out, w_out, "dense gat_forward out"), sum=_close(esum, w_sum, "dense edge_sum"),
+                max=_close(emax[has], w_max[deg > 0], "dense edge_max"), gf=_close(gf, w_gf, "dense grad_feat"),
+                gr=_close(gr, w_gr, "dense grad_attn_row"), gc=_close(gc, w_gc, "dense grad_attn_col"))
+    assert bool((emax[~has] < -9e37).all())
+    print({k: f"{v:.1e}" for k, v in errs.items()})
+    gat.USE_BLOCK_PLAN = False
+    try:
+        out_n, emax_n, esum_n, mask_n = gat.gat_forward(ar, ac, row_ptr, col_ind, 0.2, X, 0.0)
+        gf_n, gr_n, gc_n = gat.gat_backward(0.2, 0.0, row_ptr, col_ind, col_ptr, row_ind, val_idx, emax_n, esum_n, mask_n,
+                                            X, ar, ac, dO)
+    finally:
+        gat.USE_BLOCK_PLAN = True
+    for a, b in ((out, out_n), (gf, gf_n), (gr, gr_n), (gc, gc_n), (esum, esum_n)):
+        assert torch.allclose(a, b, atol=2e-4, rtol=1e-3)
+    assert not torch.equal(out, out_n)                                       # two different code paths did run
+    # a batch with one non-dense range keeps the general kernels for the whole call (all-or-nothing dispatch)
+    s_, d_ = er(40, 0.6)
+    g2 = batch(graphs[:3] + [Graph(np.concatenate([s_, s_[:1]]), np.concatenate([d_, d_[:1]]), 40)]).to(DEV)
+    A, rows, row_ptr, col_ind, val, col_ptr, row_ind, val_idx, smem = preprocess_Hyper_fw_bw(g2)
+    m2 = g2.num_nodes()
+    ar, ac, X = S.gat_features(m2, h, f, seed=9, device=DEV)
+    out2, emax2, esum2, _ = gat.gat_forward(ar, ac, row_ptr, col_ind, 0.2, X, 0.0)
+    assert row_ptr._dfgnn_plans[f].num_dense < row_ptr._dfgnn_plans[f].num_fit
+    w2, _, _ = oracle_mod.gat_train_forward(n_(row_ptr), n_(col_ind), n_(ar), n_(ac), 0.2, n_(X))
+    _close(out2, w2, "mixed batch gat_forward")
