@@ -4,7 +4,9 @@ Same function names, return tuples and `--format` dispatch as the reference's DF
 (:52-57 g_to_SPmatrix, :66-100 preprocess_CSR/Hyper, :116-142 preprocess_Hyper_fw_bw,
 :145-162 preprocess_softmax, :362-491 load_*).  COO -> CSR/CSC is done with torch sorts on whatever
 device the graph lives on; index arrays come out int32, values fp32 (all ones, like
-`dglsp.spmatrix`'s default).
+`dglsp.spmatrix`'s default).  Graphs that live on a CUDA device are converted by the native GPU preprocessing
+(dfgnn_preprocess.coo_to_hyper -> include/dfgnn.h dfgnn_preprocess_hyper: two short radix sorts); the arrays are the
+same either way (tests/test_gpu_parity.py::test_native_preprocess_matches_torch_path).
 
 `smem_consume` keeps the reference's formula (128 neighbours/row guess) purely for signature
 compatibility: the kernels size LDS per workgroup themselves and never overflow.
@@ -35,14 +37,33 @@ def _csr_parts(A):
     return row_ptr.int(), col_ind.int(), A.val[val_idx]
 
 
+def _unit_val(nnz, device):
+    """A.val[val_idx] of an unweighted adjacency (g_to_SPmatrix: dglsp.spmatrix's default ones), without the
+    gather; marked as all-ones for the binding (fused_gtconv val_ptr) so that it is not re-checked per batch."""
+    val = torch.ones(nnz, dtype=torch.float32, device=device)
+    val._dfgnn_unit = (val._version, True)
+    return val
+
+
+def _native(A, csc):
+    import dfgnn_preprocess
+    return dfgnn_preprocess.coo_to_hyper(A.row, A.col, A.shape[0], csc=csc)
+
+
 def preprocess_CSR(g, **args):
     A, max_neigh = g_to_SPmatrix(g)
+    if A.row.is_cuda:
+        row_ptr, col_ind, _, _ = _native(A, csc=False)
+        return row_ptr, col_ind, _unit_val(A.nnz, A.device), _round_up(max_neigh, WARP_SIZE)
     row_ptr, col_ind, val = _csr_parts(A)
     return row_ptr, col_ind, val, _round_up(max_neigh, WARP_SIZE)
 
 
 def preprocess_Hyper(g, **args):
     A, max_neigh = g_to_SPmatrix(g)
+    if A.row.is_cuda:
+        row_ptr, col_ind, rows, _ = _native(A, csc=False)
+        return row_ptr, col_ind, rows, _unit_val(A.nnz, A.device), _round_up(max_neigh * 8, WARP_SIZE)
     rows = torch.sort(A.row.int()).values
     row_ptr, col_ind, val = _csr_parts(A)
     return row_ptr, col_ind, rows, val, _round_up(max_neigh * 8, WARP_SIZE)
@@ -50,6 +71,9 @@ def preprocess_Hyper(g, **args):
 
 def preprocess_softmax(g, **args):
     A, max_neigh = g_to_SPmatrix(g)
+    if A.row.is_cuda:
+        row_ptr, col_ind, rows, _ = _native(A, csc=False)
+        return row_ptr, col_ind, rows, _unit_val(A.nnz, A.device), _round_up(max_neigh, WARP_SIZE)
     rows = torch.sort(A.row.int()).values
     row_ptr, col_ind, val = _csr_parts(A)
     return row_ptr, col_ind, rows, val, _round_up(max_neigh, WARP_SIZE)
@@ -59,6 +83,10 @@ def preprocess_Hyper_fw_bw(g, fused=True):
     A, max_neigh = g_to_SPmatrix(g)
     if not fused:
         return A, None, None, None, None, None, None, None, None
+    if A.row.is_cuda:
+        row_ptr, col_ind, rows, _, col_ptr, row_ind, val_idx = _native(A, csc=True)
+        return (A, rows, row_ptr, col_ind, _unit_val(A.nnz, A.device), col_ptr, row_ind, val_idx,
+                _round_up(max_neigh * 8, WARP_SIZE))
     rows = torch.sort(A.row.int()).values
     row_ptr, col_ind, val = _csr_parts(A)
     A_csr = dglsp.from_csr(indptr=row_ptr, indices=col_ind, val=val, shape=A.shape)

@@ -16,6 +16,7 @@ _vp, _i, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
 # symbol -> argtypes; mirrors include/dfgnn.h one to one (checked by tests/test_capi_symbols.py)
 SIGNATURES = {
     "dfgnn_plan_build": [_i, _i, _i] + [_vp] * 5,
+    "dfgnn_preprocess_hyper": [_i, _i, _vp, _vp, _i] + [_vp] * 8 + [ctypes.c_size_t, _vp],
     "dfgnn_gt_hyper_fwd": [_i, _i, _i, _i] + [_vp] * 13,
     "dfgnn_gt_bwd": [_i, _i, _i, _i] + [_vp] * 19,
     "dfgnn_gt_bwd_rows": [_i, _i, _i, _i] + [_vp] * 11,
@@ -60,6 +61,8 @@ def lib():
         L.dfgnn_abi_version.restype = ctypes.c_int
         L.dfgnn_plan_ints.argtypes = [ctypes.c_int]
         L.dfgnn_plan_ints.restype = ctypes.c_size_t
+        L.dfgnn_preprocess_ws_bytes.argtypes = [ctypes.c_int, ctypes.c_int]
+        L.dfgnn_preprocess_ws_bytes.restype = ctypes.c_size_t
         _lib = L
     return _lib
 

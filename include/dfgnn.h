@@ -65,6 +65,25 @@ size_t dfgnn_plan_ints(int m);
 int dfgnn_plan_build(int m, int nnz, int f, const int *row_ptr, const int *col_ind, int *plan,
                      int *meta_host, dfgnn_stream_t stream);
 
+/* ---- graph preprocessing on the GPU -----------------------------------------------------------------
+ * COO edge list -> the arrays of the reference's preprocess_Hyper / preprocess_Hyper_fw_bw
+ * (DFGNN/layers/util.py:82-100, 116-142: A.csr(), torch.sort(A.row), dglsp.from_csr(...).csc()), which the
+ * reference counts inside a training epoch (DFGNN/script/train/train_batch_graph_timing.py:115-143).
+ *   src, dst    node ids of the nnz edges (row = src, column = dst, DFGNN/layers/util.py:53-56); int64 when
+ *               idx64 != 0 (DGL's default idtype), else int32; ids are clamped to [0, m)
+ *   row_ptr int32[m+1], col_ind int32[nnz], rows int32[nnz]: CSR = stable sort by row (COO order kept inside a
+ *               row), rows = the sorted row ids
+ *   edge_order  int32[nnz]: COO position of each CSR slot (A.csr()'s value indices: val = A.val[edge_order])
+ *   col_ptr int32[m+1], row_ind int32[nnz], val_idx int32[nnz]: CSC = stable sort of the CSR list by column,
+ *               val_idx = CSR slot of each CSC entry; pass all three as NULL to skip the CSC half
+ *   ws          device workspace of dfgnn_preprocess_ws_bytes(m, nnz) bytes
+ * No host synchronisation, no allocation.  Two rocPRIM radix sorts over the ceil(log2 m) low key bits + three
+ * small kernels. */
+size_t dfgnn_preprocess_ws_bytes(int m, int nnz);
+int dfgnn_preprocess_hyper(int m, int nnz, const void *src, const void *dst, int idx64, int *row_ptr,
+                           int *col_ind, int *rows, int *edge_order, int *col_ptr, int *row_ind,
+                           int *val_idx, void *ws, size_t ws_bytes, dfgnn_stream_t stream);
+
 /* ---- GT (graph transformer) ------------------------------------------------------------------
  * replaces gt_hyper_inference  (DFGNN/src/fused_gtconv/fused_gtconv.cpp:278-314,
  *                               fused_gtconv_hyper.cu:679-725) when attn_edge == NULL, and

@@ -678,3 +678,64 @@ def test_gat_train_dense_every_geometry(oracle_mod, h, f):
     assert row_ptr._dfgnn_plans[f].num_dense < row_ptr._dfgnn_plans[f].num_fit
     w2, _, _ = oracle_mod.gat_train_forward(n_(row_ptr), n_(col_ind), n_(ar), n_(ac), 0.2, n_(X))
     _close(out2, w2, "mixed batch gat_forward")
+
+
+# ---- GPU-side preprocessing: COO -> CSR / rows / CSC through dfgnn_preprocess_hyper ----------
+@pytest.mark.parametrize("case", ["pattern", "random_dups", "isolated_tail", "int32_ids", "one_heavy_row", "no_edges",
+                                  "single_node_loop"])
+def test_native_preprocess_matches_torch_path(oracle_mod, case):
+    """Bit-exact (integer work): the native GPU preprocessing against the numpy oracle of the reference's
+    preprocess_Hyper_fw_bw arrays (oracle.coo_to_hyper, itself checked against scipy in tests/test_host.py) and against
+    the torch path the same functions take for CPU graphs."""
+    import dfgnn_preprocess
+    from DFGNN.layers import preprocess_Hyper_fw_bw
+    from DFGNN.layers.util import preprocess_CSR, preprocess_Hyper, preprocess_softmax
+    from DFGNN.utils import Graph
+    from DFGNN.utils import synthetic as S
+    rng = np.random.default_rng(len(case))
+    dtype = torch.int64
+    if case == "pattern":
+        g = S.pattern_like(batch_size=48, seed=3)
+        src, dst = (t.numpy() for t in g.edges())
+        n = g.num_nodes()
+    elif case == "random_dups":
+        n = 700
+        src, dst = rng.integers(0, n, 20000), rng.integers(0, n, 20000)
+        src[5000:6000], dst[5000:6000] = src[:1000], dst[:1000]          # duplicate edges, far apart in COO order
+    elif case == "isolated_tail":
+        n = 5000
+        src, dst = rng.integers(0, 40, 3000), rng.integers(0, 40, 3000)  # nodes 40.. have no edges at all
+    elif case == "int32_ids":
+        n = 300
+        src, dst = rng.integers(0, n, 4000), rng.integers(0, n, 4000)
+        dtype = torch.int32
+    elif case == "one_heavy_row":
+        n = 1000
+        src = np.concatenate([np.full(50000, 7), rng.integers(0, n, 2000)])
+        dst = np.concatenate([rng.integers(0, n, 50000), np.full(2000, 999)])
+    elif case == "no_edges":
+        n = 17
+        src = dst = np.zeros(0, np.int64)
+    else:
+        n = 1
+        src = dst = np.zeros(3, np.int64)
+    want = oracle_mod.coo_to_hyper(src, dst, n)
+    ts, td = torch.from_numpy(src).to(dtype).to(DEV), torch.from_numpy(dst).to(dtype).to(DEV)
+    got = dfgnn_preprocess.coo_to_hyper(ts, td, n, csc=True)
+    for t, key in zip(got, ("row_ptr", "col_ind", "rows", "edge_order", "col_ptr", "row_ind", "val_idx")):
+        assert t.dtype == torch.int32
+        np.testing.assert_array_equal(t.cpu().numpy(), want[key], err_msg=f"{case}:{key}")
+    half = dfgnn_preprocess.coo_to_hyper(ts, td, n, csc=False)
+    assert len(half) == 4 and all(torch.equal(a, b) for a, b in zip(half, got[:4]))
+    # the preprocess_* functions: GPU graph (native) == CPU graph (torch restatement of dgl.sparse)
+    gc = Graph(src, dst, n)
+    gg = gc.to(DEV)
+    for fn in (preprocess_CSR, preprocess_Hyper, preprocess_softmax, preprocess_Hyper_fw_bw):
+        a, b = fn(gg), fn(gc)
+        assert len(a) == len(b)
+        for x, y in zip(a, b):
+            if torch.is_tensor(x):
+                assert x.dtype == y.dtype and torch.equal(x.cpu(), y), (case, fn.__name__)
+            elif isinstance(x, int):
+                assert x == y
+    _loaded_native()
