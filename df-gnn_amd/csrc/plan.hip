@@ -17,11 +17,24 @@
 //   [12 .. 12+2m)       fit ranges   (n0, n1 | kPlanEdgeGlobal | kPlanDense) pairs: dense ones first, each group
 //                                    largest first
 //   [12+2m .. 12+4m)    spill chunks (r0, r1) pairs, r1 - r0 <= kHyperRows
-//   [12+4m .. )         scratch: lo[m], hi[m], bounds[m+1], unsorted[m+1]
+//   [12+4m .. )         scratch: pairs[m] (cover, bad) as int2, bounds[m+1], count, rocPRIM temporary storage
+//
+// Build (all on the GPU, four steps, no host round trip before the final header copy):
+//   1. plan_row_extent_kernel  a 16-lane group per row: column extent [lo, hi] of the row, duplicate-edge check;
+//                              the row blocks every cut lo <= i < hi between rows i and i+1: diff[lo] += 1,
+//                              diff[hi] -= 1 (integer atomics)
+//   2. rocprim::inclusive_scan of (diff, has-duplicate) pairs  ->  cover[i] = rows blocking cut i, bad[i] = rows with a
+//                              duplicate edge up to i
+//   3. rocprim::select         the open cuts (cover == 0) = ends of the natural closed ranges, in order
+//   4. plan_cut_kernel         one workgroup: greedy merge of the natural ranges (a serial walk over LDS copies),
+//                              classification, largest-first sort
 //
 // "Dense" (gt_dense.hip, dfgnn_dense.hpp): at most 255 nodes, at least one edge per 32 node pairs, f in {32, 64, 128}
 // and no duplicate edge in any row of the range -- the one thing a dense mask cannot represent.
+#include <cstring>
 #include <type_traits>
+
+#include <rocprim/rocprim.hpp>
 
 #include "../../include/dfgnn.h"
 #include "dfgnn_launch.hpp"
@@ -30,144 +43,99 @@ namespace dfgnn {
 
 constexpr int kPlanThreads = 1024;
 
-__global__ void plan_row_extent_kernel(int m, const int *__restrict__ row_ptr, const int *__restrict__ col_ind,
-                                       int *__restrict__ lo, int *__restrict__ hi, int *__restrict__ unsorted) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= m) return;
+struct PlanPair {
+  int cover, bad;  // before the scan: (diff, row has a duplicate edge); after: inclusive prefix sums
+};
+struct PlanPairAdd {
+  __host__ __device__ PlanPair operator()(const PlanPair &a, const PlanPair &b) const {
+    return PlanPair{a.cover + b.cover, a.bad + b.bad};
+  }
+};
+struct PlanCutOpen {  // flag iterator of the select: cut after row i is open
+  const PlanPair *pairs;
+  __host__ __device__ bool operator()(int i) const { return pairs[i].cover == 0; }
+};
+
+constexpr int kExtentLanes = 16;  // lanes per row in plan_row_extent_kernel
+
+// pairs must be zero on entry.
+__global__ __launch_bounds__(256) void plan_row_extent_kernel(int m, const int *__restrict__ row_ptr,
+                                                              const int *__restrict__ col_ind, PlanPair *pairs) {
+  const int i = (blockIdx.x * blockDim.x + threadIdx.x) / kExtentLanes;
+  const int gl = threadIdx.x % kExtentLanes;
+  if (i >= m) return;  // (whole groups leave together: 256 % 16 == 0)
   const int ea = row_ptr[i], eb = row_ptr[i + 1];
   int cl = i, ch = i;
-  for (int e = ea; e < eb; ++e) {
+  for (int e = ea + gl; e < eb; e += kExtentLanes) {
     const int c = col_ind[e];
     cl = min(cl, c);
     ch = max(ch, c);
   }
-  lo[i] = cl;
-  hi[i] = ch;
+#pragma unroll
+  for (int o = 1; o < kExtentLanes; o <<= 1) {
+    cl = min(cl, __shfl_xor(cl, o, kExtentLanes));
+    ch = max(ch, __shfl_xor(ch, o, kExtentLanes));
+  }
   // Duplicate columns in the row?  Only rows that could sit in a dense range matter (the range holds cl .. ch, so
-  // its span and its length are below 256): those are checked against a 256-bit map of the columns seen so far.
+  // its span and its length are below 256): every lane marks its columns in a 256-bit map; the row has a duplicate
+  // iff the union of the maps has fewer bits than the row has edges.
   int bad = 1;
   if (ch - cl < 256 && eb - ea < 256) {
     unsigned long long w0 = 0, w1 = 0, w2 = 0, w3 = 0;
-    bad = 0;
-    for (int e = ea; e < eb; ++e) {
+    for (int e = ea + gl; e < eb; e += kExtentLanes) {
       const int k = col_ind[e] - cl;
       const unsigned long long bit = 1ull << (k & 63);
       const int q = k >> 6;
-      const unsigned long long cur = q == 0 ? w0 : q == 1 ? w1 : q == 2 ? w2 : w3;
-      bad |= (cur & bit) ? 1 : 0;
       w0 |= q == 0 ? bit : 0;
       w1 |= q == 1 ? bit : 0;
       w2 |= q == 2 ? bit : 0;
       w3 |= q == 3 ? bit : 0;
     }
+#pragma unroll
+    for (int o = 1; o < kExtentLanes; o <<= 1) {
+      w0 |= __shfl_xor(w0, o, kExtentLanes);
+      w1 |= __shfl_xor(w1, o, kExtentLanes);
+      w2 |= __shfl_xor(w2, o, kExtentLanes);
+      w3 |= __shfl_xor(w3, o, kExtentLanes);
+    }
+    bad = (__popcll(w0) + __popcll(w1) + __popcll(w2) + __popcll(w3) != eb - ea) ? 1 : 0;
   }
-  unsorted[i] = bad;  // 1: the row has a duplicate edge (or is too wide / long to be part of a dense range)
+  if (gl == 0) {
+    pairs[i].bad = bad;  // 1: the row has a duplicate edge (or is too wide / long to be part of a dense range)
+    if (ch > cl) {       // the row blocks the cuts cl .. ch - 1
+      atomicAdd(&pairs[cl].cover, 1);
+      atomicAdd(&pairs[ch].cover, -1);
+    }
+  }
 }
 
-// In-place scan over m elements by the whole workgroup with coalesced accesses: wave w owns a contiguous span
-// (a multiple of 64 long), its lanes step through it 64 elements at a time (FORWARD: ascending; else descending, i.e.
-// a suffix scan); a wave-level shuffle scan plus a running carry gives every element its inclusive and exclusive
-// value: store(i, inclusive, exclusive).  load(i) may compute the element (fused flag evaluation).
-// Every thread must call it; it ends with a __syncthreads() (global writes of the pass are visible to the next).
-template <bool FORWARD, class Op, class Load, class Store>
-__device__ __forceinline__ void plan_block_scan(int m, int identity, int *wave_tot, Op op, Load load, Store store) {
-  constexpr int kWaves = kPlanThreads / kWave;
-  const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x / kWave;
-  const int span = ((m + kWaves * kWave - 1) / (kWaves * kWave)) * kWave;
-  const int r0 = min(m, w * span), r1 = min(m, r0 + span);
-  auto index = [&](int k) { return FORWARD ? r0 + k : r1 - 1 - k; };  // k-th element of this wave's span, scan order
-  constexpr int UNR = 8;  // elements per lane in flight: the loop is bound by the latency of its loads
-  int tot = identity;
-  for (int base = 0; base < r1 - r0; base += UNR * kWave) {
-    int x[UNR];
-#pragma unroll
-    for (int u = 0; u < UNR; ++u) {
-      const int k = base + u * kWave + lane;
-      x[u] = (k < r1 - r0) ? load(index(k)) : identity;
-    }
-#pragma unroll
-    for (int u = 0; u < UNR; ++u) tot = op(tot, x[u]);
-  }
-#pragma unroll
-  for (int o = kWave / 2; o > 0; o >>= 1) tot = op(tot, __shfl_xor(tot, o, kWave));
-  if (lane == 0) wave_tot[w] = tot;
-  __syncthreads();
-  int carry = identity;
-  for (int k = 0; k < kWaves; ++k)
-    if (FORWARD ? k < w : k > w) carry = op(carry, wave_tot[k]);
-  for (int base = 0; base < r1 - r0; base += UNR * kWave) {
-    int x[UNR];
-#pragma unroll
-    for (int u = 0; u < UNR; ++u) {
-      const int k = base + u * kWave + lane;
-      x[u] = (k < r1 - r0) ? load(index(k)) : identity;
-    }
-#pragma unroll
-    for (int u = 0; u < UNR; ++u) {
-      const int k = base + u * kWave + lane;
-      int v = x[u];
-#pragma unroll
-      for (int o = 1; o < kWave; o <<= 1) {
-        const int up = __shfl_up(v, o, kWave);
-        if (lane >= o) v = op(v, up);
-      }
-      const int incl = op(carry, v);
-      int excl = __shfl_up(incl, 1, kWave);
-      if (lane == 0) excl = carry;
-      if (k < r1 - r0) store(index(k), incl, excl);
-      carry = __shfl(incl, kWave - 1, kWave);
-    }
-  }
-  __syncthreads();
-}
-
-// One workgroup.  (1) hi <- inclusive prefix max, lo <- inclusive suffix min.  (2) boundary after row i
-// iff pmax[i] <= i and smin[i+1] >= i+1.  (3) thread 0 merges consecutive closed ranges greedily while
-// they fit the LDS budget and emits fit blocks / spill chunks.
+// One workgroup: thread 0 merges consecutive natural ranges (bounds[0 .. *count): their ends, ascending) greedily
+// while they fit the LDS budget and emits fit blocks / spill chunks; then all threads sort the fit list.
 __global__ __launch_bounds__(kPlanThreads) void plan_cut_kernel(int m, int nnz, int f, int budget_bytes,
                                                                 int merge_nodes,
-                                                                const int *__restrict__ row_ptr, int *plan) {
+                                                                const int *__restrict__ row_ptr, int *plan,
+                                                                const PlanPair *pairs, const int *bounds,
+                                                                const int *count) {
   int *hdr = plan;
   int *fit = plan + kPlanHeader;
   int *spill = fit + 2 * (size_t)m;
-  int *lo = spill + 2 * (size_t)m;
-  int *hi = lo + m;
-  int *bounds = hi + m;  // [m + 1] ends of the natural closed ranges
-  int *unsorted = bounds + m + 1;  // [m + 1] in: per-row 'has a duplicate edge' flag, out: exclusive prefix count
   const int t = threadIdx.x;
-  __shared__ int wave_tot[kPlanThreads / kWave];
-
-  // (1) prefix max of hi, suffix min of lo, exclusive prefix count of the rows with duplicate edges
-  plan_block_scan<true>(m, -1, wave_tot, [](int a, int b) { return max(a, b); }, [&](int i) { return hi[i]; },
-                        [&](int i, int incl, int) { hi[i] = incl; });
-  plan_block_scan<false>(m, m, wave_tot, [](int a, int b) { return min(a, b); }, [&](int i) { return lo[i]; },
-                         [&](int i, int incl, int) { lo[i] = incl; });
-  plan_block_scan<true>(m, 0, wave_tot, [](int a, int b) { return a + b; }, [&](int i) { return unsorted[i]; },
-                        [&](int i, int incl, int excl) {
-                          unsorted[i] = excl;
-                          if (i == m - 1) unsorted[m] = incl;
-                        });
-  // (2) a boundary after row i iff pmax[i] <= i and smin[i+1] >= i+1: number them, write the ends of the natural ranges
-  plan_block_scan<true>(m, 0, wave_tot, [](int a, int b) { return a + b; },
-                        [&](int i) { return (hi[i] <= i && (i + 1 == m || lo[i + 1] >= i + 1)) ? 1 : 0; },
-                        [&](int i, int incl, int excl) {
-                          if (incl != excl) bounds[excl] = i + 1;
-                          if (i == m - 1) hdr[7] = incl;  // number of natural ranges (temporary)
-                        });
+  // rows with a duplicate edge before row `end`
+  auto bad_before = [&](int end) { return end > 0 ? pairs[end - 1].bad : 0; };
 
   // Greedy merge by thread 0.  The ends of the natural ranges and their row_ptr values are first copied to
   // LDS (when there are few enough) so the serial walk does not pay a global-memory round trip per range.
   constexpr int kCache = 4096;
   __shared__ int s_end[kCache], s_rp[kCache], s_bad[kCache];
   __shared__ int s_nfit;
-  const int nb = hdr[7];
+  const int nb = *count;
   const bool cached = nb <= kCache;
   if (cached)
     for (int k = t; k < nb; k += kPlanThreads) {
       const int en = bounds[k];
       s_end[k] = en;
       s_rp[k] = row_ptr[en];
-      s_bad[k] = unsorted[en];  // rows with duplicate edges before the end of natural range k
+      s_bad[k] = bad_before(en);  // rows with duplicate edges before the end of natural range k
     }
   __syncthreads();
   if (t == 0) {
@@ -212,7 +180,7 @@ __global__ __launch_bounds__(kPlanThreads) void plan_cut_kernel(int m, int nnz, 
       } else {
         end = bounds[k];
         rp_end = row_ptr[end];
-        bad_end = unsorted[end];
+        bad_end = bad_before(end);
       }
       const int n_one = end - prev, e_one = rp_end - rp_prev;
       if (lite(n_one, e_one) > budget_bytes) {            // not even the feature rows of this range fit
@@ -303,12 +271,13 @@ __global__ __launch_bounds__(kPlanThreads) void plan_cut_kernel(int m, int nnz, 
         }
         __syncthreads();
       }
-    int *tmp = lo;  // lo[] and hi[] (2m ints) are free now
+    int *tmp = spill + 2 * (size_t)m;  // the pairs (2m ints) are not needed any more
     for (int i = t; i < nfit; i += kPlanThreads) {
       const int src = s_rp[i];
       tmp[2 * i] = fit[2 * src];
       tmp[2 * i + 1] = fit[2 * src + 1];
     }
+    __threadfence_block();
     __syncthreads();
     for (int i = t; i < 2 * nfit; i += kPlanThreads) fit[i] = tmp[i];
   }
@@ -320,7 +289,22 @@ using namespace dfgnn;
 
 extern "C" {
 
-size_t dfgnn_plan_ints(int m) { return m < 0 ? 0 : kPlanHeader + 8 * (size_t)m + 2; }
+// rocPRIM temporary storage (bytes) shared by the scan and the select over m elements
+static size_t plan_temp_bytes(int m) {
+  size_t a = 0, b = 0;
+  (void)rocprim::inclusive_scan(nullptr, a, (PlanPair *)nullptr, (PlanPair *)nullptr, (size_t)m, PlanPairAdd{},
+                                (hipStream_t) nullptr);
+  auto flags = rocprim::make_transform_iterator(rocprim::counting_iterator<int>(0), PlanCutOpen{nullptr});
+  (void)rocprim::select(nullptr, b, rocprim::counting_iterator<int>(1), flags, (int *)nullptr, (int *)nullptr, (size_t)m,
+                        (hipStream_t) nullptr);
+  return ((a > b ? a : b) + 255) & ~(size_t)255;
+}
+
+// scratch after the fit / spill lists: pairs (2m ints), bounds (m + 1), count (1 + 2 pad), temp (aligned to 256 B)
+size_t dfgnn_plan_ints(int m) {
+  if (m < 0) return 0;
+  return kPlanHeader + 7 * (size_t)m + 4 + (plan_temp_bytes(m) + 256) / sizeof(int);
+}
 
 int dfgnn_plan_build(int m, int nnz, int f, const int *row_ptr, const int *col_ind, int *plan, int *meta_host,
                      dfgnn_stream_t stream) {
@@ -330,15 +314,25 @@ int dfgnn_plan_build(int m, int nnz, int f, const int *row_ptr, const int *col_i
   meta_host[4] = m; meta_host[5] = nnz; meta_host[6] = f; meta_host[7] = kBlockLdsBudget;
   if (m == 0) return 0;
   if (!row_ptr || (nnz > 0 && !col_ind)) return kErrBadArg;
-  int *lo = plan + kPlanHeader + 4 * (size_t)m;
-  int *hi = lo + m;
-  int *unsorted = hi + m + (m + 1);
-  plan_row_extent_kernel<<<(m + 255) / 256, 256, 0, s>>>(m, row_ptr, col_ind, lo, hi, unsorted);
+  PlanPair *pairs = reinterpret_cast<PlanPair *>(plan + kPlanHeader + 4 * (size_t)m);
+  int *bounds = plan + kPlanHeader + 6 * (size_t)m;
+  int *count = bounds + m + 1;
+  void *temp = reinterpret_cast<void *>((reinterpret_cast<uintptr_t>(count + 3) + 255) & ~(uintptr_t)255);
+  size_t temp_bytes = plan_temp_bytes(m);
+  if (hipError_t rc = hipMemsetAsync(pairs, 0, (size_t)m * sizeof(PlanPair), s)) return (int)rc;
+  const long threads = (long)m * kExtentLanes;
+  plan_row_extent_kernel<<<(unsigned)((threads + 255) / 256), 256, 0, s>>>(m, row_ptr, col_ind, pairs);
   if (int rc = launch_status()) return rc;
+  size_t tb = temp_bytes;
+  if (hipError_t rc = rocprim::inclusive_scan(temp, tb, pairs, pairs, (size_t)m, PlanPairAdd{}, s)) return (int)rc;
+  auto flags = rocprim::make_transform_iterator(rocprim::counting_iterator<int>(0), PlanCutOpen{pairs});
+  tb = temp_bytes;
+  if (hipError_t rc = rocprim::select(temp, tb, rocprim::counting_iterator<int>(1), flags, bounds, count, (size_t)m, s))
+    return (int)rc;
   // Widths with a matrix-core form: a merged range costs n^2 there and needs a second pass over 128-row blocks past
   // 128 nodes, so small graphs are only merged up to 128 nodes.
   const int merge_nodes = (f == 32 || f == 64 || f == 128) ? 128 : kBlockMergeNodes;
-  plan_cut_kernel<<<1, kPlanThreads, 0, s>>>(m, nnz, f, kBlockLdsBudget, merge_nodes, row_ptr, plan);
+  plan_cut_kernel<<<1, kPlanThreads, 0, s>>>(m, nnz, f, kBlockLdsBudget, merge_nodes, row_ptr, plan, pairs, bounds, count);
   if (int rc = launch_status()) return rc;
   if (hipError_t rc = hipMemcpyAsync(meta_host, plan, kPlanHeader * sizeof(int), hipMemcpyDeviceToHost, s)) return (int)rc;
   return (int)hipStreamSynchronize(s);

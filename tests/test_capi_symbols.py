@@ -31,7 +31,7 @@ def test_loader_signatures_cover_header():
     assert lib.dfgnn_abi_version() == 6
     assert b"bad argument" in lib.dfgnn_error_string(-1)
     assert b"unsupported" in lib.dfgnn_error_string(-2)
-    assert lib.dfgnn_plan_ints(10) == 12 + 8 * 10 + 2
+    assert lib.dfgnn_plan_ints(10) >= 12 + 7 * 10 + 4          # header + lists + scratch (+ rocPRIM temporary storage)
 
 
 def test_header_arity_matches_loader():
