@@ -109,57 +109,157 @@ __global__ __launch_bounds__(256) void plan_row_extent_kernel(int m, const int *
   }
 }
 
-// One workgroup: thread 0 merges consecutive natural ranges (bounds[0 .. *count): their ends, ascending) greedily
-// while they fit the LDS budget and emits fit blocks / spill chunks; then all threads sort the fit list.
+// LDS bytes of a range of n nodes holding ed edges: resident rows + 1/sum + rebased row_ptr + narrowed column ids,
+// plus (full only) the per-edge fp32 array.  Layout: dfgnn_block.hpp:carve_block_lds.  (32-bit arithmetic on clamped
+// sizes: anything clamped is far over the budget anyway.)
+__device__ __forceinline__ int plan_lite_bytes(int n, int ed, int f) {
+  n = min(n, 1 << 16);
+  ed = min(ed, 1 << 24);
+  return n * (4 * f + 8) + ed * (n <= 256 ? 1 : 2);
+}
+__device__ __forceinline__ int plan_full_bytes(int n, int ed, int f) { return plan_lite_bytes(n, ed, f) + 4 * min(ed, 1 << 24); }
+
+constexpr int kPlanCache = 4096;  // natural ranges handled by the parallel merge / the sort (more: serial fallback)
+enum : unsigned char { kClsNormal = 0, kClsGlobal = 1, kClsSpill = 2 };
+
+// One workgroup.  Natural ranges (bounds[0 .. *count): their ends, ascending) are merged greedily, left to right,
+// while the merged range fits the LDS budget and merge_nodes; a range whose rows do not fit is cut into spill chunks,
+// one whose per-edge array does not fit stays alone ("edge-global").  Up to kPlanCache ranges this runs in parallel:
+//   A  class of every range                                        (thread per range)
+//   B  next[k] = where the greedy group that STARTS at k ends      (thread per range; the group condition is monotone)
+//   C  the group starts: 0, next[0], next[next[0]], ...            (one thread, one LDS read per group)
+//   D  exclusive scans of the fit / spill-chunk counts, output     (thread per range)
+// which gives exactly the lists of the serial walk (kept below for longer lists).  Then all threads sort the fit list.
 __global__ __launch_bounds__(kPlanThreads) void plan_cut_kernel(int m, int nnz, int f, int budget_bytes,
                                                                 int merge_nodes,
                                                                 const int *__restrict__ row_ptr, int *plan,
                                                                 const PlanPair *pairs, const int *bounds,
                                                                 const int *count) {
+  extern __shared__ __attribute__((aligned(16))) int plan_lds[];
+  int *s_end = plan_lds;                    // [kPlanCache + 1] prefix form: range k = [s_end[k], s_end[k + 1])
+  int *s_rp = s_end + kPlanCache + 1;       // [kPlanCache + 1] row_ptr at those nodes
+  int *s_bad = s_rp + kPlanCache + 1;       // [kPlanCache + 1] rows with a duplicate edge before those nodes
+  int *s_next = s_bad + kPlanCache + 1;     // [kPlanCache]
+  int *s_tot = s_next + kPlanCache;         // [2][kPlanThreads] scan scratch
+  unsigned char *s_cls = reinterpret_cast<unsigned char *>(s_tot + 2 * kPlanThreads);  // [kPlanCache]
+  unsigned char *s_start = s_cls + kPlanCache;                                          // [kPlanCache]
+  __shared__ int s_nfit, s_stat[4];
   int *hdr = plan;
   int *fit = plan + kPlanHeader;
   int *spill = fit + 2 * (size_t)m;
   const int t = threadIdx.x;
+  const bool dense_f = (f == 32 || f == 64 || f == 128);
   // rows with a duplicate edge before row `end`
   auto bad_before = [&](int end) { return end > 0 ? pairs[end - 1].bad : 0; };
+  // a fit entry (n0, n1 | flags) for the range [n0, n1) holding ed edges; returns its flags
+  auto fit_entry = [&](int slot, int n0, int n1, int ed, int bad0, int bad1) {
+    const int nn = n1 - n0;
+    const bool edge_global = plan_full_bytes(nn, ed, f) > budget_bytes;  // only ever true for an unmerged range
+    const bool dense = dense_f && nn <= 255 && min(ed, 1 << 24) * 32 >= nn * nn && bad1 == bad0;
+    const int flags = (edge_global ? kPlanEdgeGlobal : 0) | (dense ? kPlanDense : 0);
+    fit[2 * slot] = n0;
+    fit[2 * slot + 1] = n1 | flags;
+    return flags;
+  };
 
-  // Greedy merge by thread 0.  The ends of the natural ranges and their row_ptr values are first copied to
-  // LDS (when there are few enough) so the serial walk does not pay a global-memory round trip per range.
-  constexpr int kCache = 4096;
-  __shared__ int s_end[kCache], s_rp[kCache], s_bad[kCache];
-  __shared__ int s_nfit;
   const int nb = *count;
-  const bool cached = nb <= kCache;
-  if (cached)
-    for (int k = t; k < nb; k += kPlanThreads) {
-      const int en = bounds[k];
+  if (nb <= kPlanCache) {
+    if (t < 4) s_stat[t] = 0;
+    for (int k = t; k <= nb; k += kPlanThreads) {
+      const int en = k ? bounds[k - 1] : 0;
       s_end[k] = en;
       s_rp[k] = row_ptr[en];
-      s_bad[k] = bad_before(en);  // rows with duplicate edges before the end of natural range k
+      s_bad[k] = bad_before(en);
     }
-  __syncthreads();
-  if (t == 0) {
+    __syncthreads();
+    for (int k = t; k < nb; k += kPlanThreads) {  // A
+      const int n_one = s_end[k + 1] - s_end[k], e_one = s_rp[k + 1] - s_rp[k];
+      s_cls[k] = plan_lite_bytes(n_one, e_one, f) > budget_bytes   ? kClsSpill
+                 : plan_full_bytes(n_one, e_one, f) > budget_bytes ? kClsGlobal
+                                                                   : kClsNormal;
+      s_start[k] = 0;
+    }
+    __syncthreads();
+    for (int k = t; k < nb; k += kPlanThreads) {  // B
+      int j = k + 1;
+      if (s_cls[k] == kClsNormal)
+        while (j < nb && s_cls[j] == kClsNormal && s_end[j + 1] - s_end[k] <= merge_nodes &&
+               plan_full_bytes(s_end[j + 1] - s_end[k], s_rp[j + 1] - s_rp[k], f) <= budget_bytes)
+          ++j;
+      s_next[k] = j;
+    }
+    __syncthreads();
+    if (t == 0)  // C
+      for (int k = 0; k < nb; k = s_next[k]) s_start[k] = 1;
+    __syncthreads();
+    // D: every group start emits one fit entry (not for a spill range) and its spill chunks; exclusive scans number them
+    constexpr int PER = kPlanCache / kPlanThreads;
+    int cf[PER], cs[PER], tf = 0, ts = 0;
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      const int k = t * PER + u;
+      const bool st = k < nb && s_start[k];
+      const bool sp = st && s_cls[k] == kClsSpill;
+      cf[u] = tf;
+      cs[u] = ts;
+      tf += (st && !sp) ? 1 : 0;
+      ts += sp ? (s_end[k + 1] - s_end[k] + kHyperRows - 1) / kHyperRows : 0;
+    }
+    s_tot[t] = tf;
+    s_tot[kPlanThreads + t] = ts;
+    __syncthreads();
+    for (int o = 1; o < kPlanThreads; o <<= 1) {  // inclusive Hillis-Steele over the per-thread totals
+      const int a = t >= o ? s_tot[t - o] : 0, b2 = t >= o ? s_tot[kPlanThreads + t - o] : 0;
+      __syncthreads();
+      s_tot[t] += a;
+      s_tot[kPlanThreads + t] += b2;
+      __syncthreads();
+    }
+    const int base_f = s_tot[t] - tf, base_s = s_tot[kPlanThreads + t] - ts;
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      const int k = t * PER + u;
+      if (k < nb && s_start[k]) {
+        if (s_cls[k] == kClsSpill) {
+          int slot = base_s + cs[u];
+          for (int r = s_end[k]; r < s_end[k + 1]; r += kHyperRows, ++slot) {
+            spill[2 * slot] = r;
+            spill[2 * slot + 1] = min(s_end[k + 1], r + kHyperRows);
+          }
+        } else {
+          const int j = s_next[k], ed = s_rp[j] - s_rp[k];
+          const int flags = fit_entry(base_f + cf[u], s_end[k], s_end[j], ed, s_bad[k], s_bad[j]);
+          atomicMax(&s_stat[0], s_end[j] - s_end[k]);
+          atomicMax(&s_stat[1], ed);
+          if (flags & kPlanEdgeGlobal) atomicAdd(&s_stat[2], 1);
+          if (flags & kPlanDense) atomicAdd(&s_stat[3], 1);
+        }
+      }
+    }
+    __syncthreads();
+    if (t == 0) {
+      const int nfit = s_tot[kPlanThreads - 1];
+      hdr[0] = nfit;
+      hdr[1] = s_tot[2 * kPlanThreads - 1];
+      hdr[2] = s_stat[0];
+      hdr[3] = s_stat[1];
+      hdr[4] = m;
+      hdr[5] = nnz;
+      hdr[6] = f;
+      hdr[7] = budget_bytes;
+      hdr[8] = s_stat[2];
+      hdr[9] = s_stat[3];
+      hdr[10] = hdr[11] = 0;
+      s_nfit = nfit;
+    }
+  } else if (t == 0) {
+    // serial walk over the global arrays (long lists of natural ranges: batches of thousands of tiny graphs)
     int nfit = 0, nspill = 0, maxn = 0, maxe = 0, nglobal = 0, ndense = 0;
-    const bool dense_f = (f == 32 || f == 64 || f == 128);
-    // LDS bytes of a range [n0, n1) holding ed edges: resident rows + 1/sum + rebased row_ptr + narrowed
-    // column ids, plus (full only) the per-edge fp32 array.  Layout: dfgnn_block.hpp:carve_block_lds.
-    // (32-bit arithmetic on clamped sizes -- this serial walk is latency-bound, and anything clamped is far over the
-    // budget anyway)
-    auto lite = [&](int n, int ed) -> int {
-      n = min(n, 1 << 16);
-      ed = min(ed, 1 << 24);
-      return n * (4 * f + 8) + ed * (n <= 256 ? 1 : 2);
-    };
-    auto full = [&](int n, int ed) -> int { return lite(n, ed) + 4 * min(ed, 1 << 24); };
     auto flush = [&](int n0, int n1, int ed, int bad0, int bad1) {
       if (n1 <= n0) return;
-      const bool edge_global = full(n1 - n0, ed) > budget_bytes;  // only ever true for an unmerged range
-      const int nn = n1 - n0;
-      const bool dense = dense_f && nn <= 255 && min(ed, 1 << 24) * 32 >= nn * nn && bad1 == bad0;
-      fit[2 * nfit] = n0;
-      fit[2 * nfit + 1] = n1 | (edge_global ? kPlanEdgeGlobal : 0) | (dense ? kPlanDense : 0);
-      nglobal += edge_global ? 1 : 0;
-      ndense += dense ? 1 : 0;
+      const int flags = fit_entry(nfit, n0, n1, ed, bad0, bad1);
+      nglobal += (flags & kPlanEdgeGlobal) ? 1 : 0;
+      ndense += (flags & kPlanDense) ? 1 : 0;
       ++nfit;
       maxn = max(maxn, n1 - n0);
       maxe = max(maxe, ed);
@@ -167,23 +267,10 @@ __global__ __launch_bounds__(kPlanThreads) void plan_cut_kernel(int m, int nnz, 
     int cur0 = 0, cur1 = 0, prev = 0;          // current merged range [cur0, cur1), previous range end
     int rp_cur0 = row_ptr[0], rp_cur1 = rp_cur0, rp_prev = rp_cur0;
     int bad_cur0 = 0, bad_cur1 = 0, bad_prev = 0;  // duplicate-edge row counts before cur0 / cur1 / prev
-    // (two instances of the walk: with a `cached ? lds : global` select per value the compiler issues the dependent
-    // global loads unconditionally -- 900 cycles per range instead of 60)
-    auto walk = [&](auto cached_c) {
-    constexpr bool kCached = decltype(cached_c)::value;
     for (int k = 0; k < nb; ++k) {
-      int end, rp_end, bad_end;
-      if constexpr (kCached) {
-        end = s_end[k];
-        rp_end = s_rp[k];
-        bad_end = s_bad[k];
-      } else {
-        end = bounds[k];
-        rp_end = row_ptr[end];
-        bad_end = bad_before(end);
-      }
+      const int end = bounds[k], rp_end = row_ptr[end], bad_end = bad_before(end);
       const int n_one = end - prev, e_one = rp_end - rp_prev;
-      if (lite(n_one, e_one) > budget_bytes) {            // not even the feature rows of this range fit
+      if (plan_lite_bytes(n_one, e_one, f) > budget_bytes) {            // not even the feature rows of this range fit
         flush(cur0, cur1, rp_cur1 - rp_cur0, bad_cur0, bad_cur1);
         for (int r = prev; r < end; r += kHyperRows) {
           spill[2 * nspill] = r;
@@ -193,13 +280,14 @@ __global__ __launch_bounds__(kPlanThreads) void plan_cut_kernel(int m, int nnz, 
         cur0 = cur1 = end;
         rp_cur0 = rp_cur1 = rp_end;
         bad_cur0 = bad_cur1 = bad_end;
-      } else if (full(n_one, e_one) > budget_bytes) {     // rows fit, the per-edge array goes to global scratch
+      } else if (plan_full_bytes(n_one, e_one, f) > budget_bytes) {     // rows fit, the per-edge array goes to global scratch
         flush(cur0, cur1, rp_cur1 - rp_cur0, bad_cur0, bad_cur1);
         flush(prev, end, e_one, bad_prev, bad_end);
         cur0 = cur1 = end;
         rp_cur0 = rp_cur1 = rp_end;
         bad_cur0 = bad_cur1 = bad_end;
-      } else if (cur1 > cur0 && (full(end - cur0, rp_end - rp_cur0) > budget_bytes || end - cur0 > merge_nodes)) {
+      } else if (cur1 > cur0 &&
+                 (plan_full_bytes(end - cur0, rp_end - rp_cur0, f) > budget_bytes || end - cur0 > merge_nodes)) {
         flush(cur0, cur1, rp_cur1 - rp_cur0, bad_cur0, bad_cur1);
         cur0 = prev;
         rp_cur0 = rp_prev;
@@ -217,9 +305,6 @@ __global__ __launch_bounds__(kPlanThreads) void plan_cut_kernel(int m, int nnz, 
       rp_prev = rp_end;
       bad_prev = bad_end;
     }
-    };
-    if (cached) walk(std::true_type{});
-    else walk(std::false_type{});
     flush(cur0, cur1, rp_cur1 - rp_cur0, bad_cur0, bad_cur1);
     hdr[0] = nfit;
     hdr[1] = nspill;
@@ -230,7 +315,7 @@ __global__ __launch_bounds__(kPlanThreads) void plan_cut_kernel(int m, int nnz, 
     hdr[6] = f;
     hdr[7] = budget_bytes;
     hdr[8] = nglobal;
-    hdr[9] = (nfit <= kCache) ? ndense : 0;  // the dense ranges are only usable once sorted to the front (below)
+    hdr[9] = (nfit <= kPlanCache) ? ndense : 0;  // the dense ranges are only usable once sorted to the front (below)
     hdr[10] = hdr[11] = 0;
     s_nfit = nfit;
   }
@@ -240,7 +325,7 @@ __global__ __launch_bounds__(kPlanThreads) void plan_cut_kernel(int m, int nnz, 
   // shortest ones): bitonic sort of (edges, index) in LDS, reusing s_end / s_rp.  Skipped for long lists,
   // where the tail is negligible anyway.
   const int nfit = s_nfit;
-  if (nfit > 1 && nfit <= kCache) {
+  if (nfit > 1 && nfit <= kPlanCache) {
     int N = 1;
     while (N < nfit) N <<= 1;
     for (int i = t; i < N; i += kPlanThreads) {
@@ -332,7 +417,13 @@ int dfgnn_plan_build(int m, int nnz, int f, const int *row_ptr, const int *col_i
   // Widths with a matrix-core form: a merged range costs n^2 there and needs a second pass over 128-row blocks past
   // 128 nodes, so small graphs are only merged up to 128 nodes.
   const int merge_nodes = (f == 32 || f == 64 || f == 128) ? 128 : kBlockMergeNodes;
-  plan_cut_kernel<<<1, kPlanThreads, 0, s>>>(m, nnz, f, kBlockLdsBudget, merge_nodes, row_ptr, plan, pairs, bounds, count);
+  constexpr size_t kCutLds = sizeof(int) * (3 * (kPlanCache + 1) + kPlanCache + 2 * kPlanThreads) + 2 * kPlanCache;
+  static_assert(kCutLds <= (size_t)kLdsBytes, "plan_cut_kernel LDS");
+  if (hipError_t rc = hipFuncSetAttribute(reinterpret_cast<const void *>(plan_cut_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)kCutLds))
+    return (int)rc;
+  plan_cut_kernel<<<1, kPlanThreads, kCutLds, s>>>(m, nnz, f, kBlockLdsBudget, merge_nodes, row_ptr, plan, pairs, bounds,
+                                                   count);
   if (int rc = launch_status()) return rc;
   if (hipError_t rc = hipMemcpyAsync(meta_host, plan, kPlanHeader * sizeof(int), hipMemcpyDeviceToHost, s)) return (int)rc;
   return (int)hipStreamSynchronize(s);
