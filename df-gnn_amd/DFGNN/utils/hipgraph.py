@@ -1,0 +1,33 @@
+"""HIP-graph capture of an operator step (MI355X-specific helper; no counterpart in the reference).
+
+Small batches (Peptides-like: ~70 us of kernels per fwd+bwd) are bound by the host side of each launch -- the
+Python binding, autograd bookkeeping and the launch itself cost more than the kernels.  Every entry point of the C ABI
+is capturable (no allocation, no host synchronisation inside, launches on the caller's stream), so a whole training
+step can be recorded once and replayed with a single hipGraphLaunch:
+
+    step = GraphedStep(lambda: fwd_bwd(Q, K, V, dO))     # warm-up (builds and caches the block plan), then capture
+    out, dQ, dK, dV = step.replay()                       # same tensors every time: copy new inputs in place
+
+The inputs are static tensors: write the next batch's features into them (`Q.copy_(...)`) before `replay()`.  The graph
+structure (index arrays, plan) is baked in, i.e. one GraphedStep per batch structure -- the case of multi-layer /
+multi-epoch training over cached batches (DFGNN/script/train/train_batch_graph_timing.py keeps its batches on the GPU).
+"""
+import torch
+
+
+class GraphedStep:
+    def __init__(self, fn, warmup=3):
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):  # warm-up off the default stream: plan build, unit-val check, allocator pools
+            for _ in range(warmup):
+                fn()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.outputs = fn()
+
+    def replay(self):
+        self.graph.replay()
+        return self.outputs

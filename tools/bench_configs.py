@@ -133,6 +133,10 @@ if "c5" in args:
             return (out,) + torch.autograd.grad(out, (Q, K, V), dO)
 
         res, sec = benchmark(step)
+        from DFGNN.utils import GraphedStep
+        graphed = GraphedStep(step)                      # the same step as one hipGraphLaunch
+        res_g, sec_g = benchmark(graphed.replay)
+        assert all(torch.equal(a, b) for a, b in zip(res, res_g))
         n = lambda t: t.detach().cpu().numpy()  # noqa: E731
         want = oracle.gt_forward(n(row_ptr), n(col_ind), n(val), n(Q), n(K), n(V))
         wq, wk, wv = oracle.gt_backward(n(row_ptr), n(col_ind), n(val), n(Q), n(K), n(V), n(dO))
@@ -141,7 +145,8 @@ if "c5" in args:
         byt = (16 * m * D + 12 * nnz + 4 * (m + 1) + 4 * heads * nnz) + (28 * m * D + 12 * heads * nnz + 16 * nnz + 8 * (m + 1))
         plan = getattr(row_ptr, "_dfgnn_plans", {}).get(f) if use_plan else None  # low-degree batches build none
         emit(config=f"C5 GT Peptides-like bs=256 dim=128 heads={heads} 'hyper' fwd+bwd plan={use_plan}", nodes=m, edges=nnz,
-             us=sec * 1e6, edges_per_s=nnz / sec, max_abs_err=err, algorithmic_GBs=byt / sec / 1e9,
+             us=sec * 1e6, edges_per_s=nnz / sec, us_hipgraph=sec_g * 1e6, edges_per_s_hipgraph=nnz / sec_g,
+             max_abs_err=err, algorithmic_GBs=byt / sec / 1e9,
              hbm_frac=byt / sec / 1e9 / HBM, plan_fit=plan.num_fit if plan else 0,
              plan_spill=plan.num_spill if plan else 0)
     _gtb.USE_BLOCK_PLAN = True
