@@ -5,8 +5,15 @@ Python binding, autograd bookkeeping and the launch itself cost more than the ke
 is capturable (no allocation, no host synchronisation inside, launches on the caller's stream), so a whole training
 step can be recorded once and replayed with a single hipGraphLaunch:
 
-    step = GraphedStep(lambda: fwd_bwd(Q, K, V, dO))     # warm-up (builds and caches the block plan), then capture
+    def fwd_bwd():                                        # explicit operator calls (fused_gtconv / fused_gatconv)
+        out, attn = fused_gtconv.gt_hyper_forward(row_ptr, col_ind, rows, val, col_ptr, row_ind, val_idx, smem, Q, K, V)
+        return [out] + fused_gtconv.gt_backward(row_ptr, col_ind, rows, val, col_ptr, row_ind, val_idx, smem, Q, K, V, attn, dO)
+    step = GraphedStep(fwd_bwd)                           # warm-up (builds and caches the block plan), then capture
     out, dQ, dK, dV = step.replay()                       # same tensors every time: copy new inputs in place
+
+Record operator calls, not `autograd.Function.apply` + `torch.autograd.grad`: capturing the autograd engine's worker
+thread is outside what this helper supports (on this ROCm / torch build it crashed in hipStreamEndCapture for the
+low-degree batches; tools/diag/hipgraph_probe.py reproduces it).
 
 The inputs are static tensors: write the next batch's features into them (`Q.copy_(...)`) before `replay()`.  The graph
 structure (index arrays, plan) is baked in, i.e. one GraphedStep per batch structure -- the case of multi-layer /

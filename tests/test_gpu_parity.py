@@ -743,10 +743,11 @@ def test_native_preprocess_matches_torch_path(oracle_mod, case):
 
 @pytest.mark.parametrize("shape", ["peptides", "pattern"])
 def test_hipgraph_capture_of_a_training_step(shape):
-    """The C ABI is capturable (no allocation / host sync inside, launches on the caller's stream): a fwd+bwd step
-    recorded into a HIP graph replays bit-identically, also after the static inputs were overwritten in place."""
+    """The C ABI is capturable (no allocation / host sync inside, launches on the caller's stream): a forward +
+    backward pair of operator calls recorded into a HIP graph replays bit-identically, also after the static inputs
+    were overwritten in place."""
+    import fused_gtconv as gt
     from DFGNN.layers import preprocess_Hyper_fw_bw
-    from DFGNN.operators.fused_gtconv import GTConvFuse_hyper
     from DFGNN.utils import GraphedStep
     from DFGNN.utils import synthetic as S
     if shape == "peptides":
@@ -755,20 +756,19 @@ def test_hipgraph_capture_of_a_training_step(shape):
         g, h, f = S.pattern_like(batch_size=24, seed=2).to(DEV), 1, 128      # plan + matrix-core kernels
     A, rows, row_ptr, col_ind, val, col_ptr, row_ind, val_idx, smem = preprocess_Hyper_fw_bw(g)
     m = g.num_nodes()
-    Q, K, V = (t.requires_grad_(True) for t in S.gt_features(m, h, f, seed=3, device=DEV))
+    Q, K, V = S.gt_features(m, h, f, seed=3, device=DEV)
     dO = torch.randn(m, h, f, device=DEV)
 
     def step():
-        out = GTConvFuse_hyper(rows, row_ptr, col_ind, val, col_ptr, row_ind, val_idx, smem, Q, K, V)
-        return (out,) + torch.autograd.grad(out, (Q, K, V), dO)
+        out, attn = gt.gt_hyper_forward(row_ptr, col_ind, rows, val, col_ptr, row_ind, val_idx, smem, Q, K, V)
+        return [out] + gt.gt_backward(row_ptr, col_ind, rows, val, col_ptr, row_ind, val_idx, smem, Q, K, V, attn, dO)
 
     eager = [t.clone() for t in step()]
     graphed = GraphedStep(step)
     for a, b in zip(eager, graphed.replay()):
         assert torch.equal(a, b)
-    with torch.no_grad():                                  # next "batch" of features, same structure
-        Q.mul_(0.5)
-        V.add_(1.0)
+    Q.mul_(0.5)                                            # next "batch" of features, same structure
+    V.add_(1.0)
     again = [t.clone() for t in graphed.replay()]
     for a, b in zip(step(), again):
         assert torch.equal(a, b)
