@@ -15,7 +15,8 @@ import torch
 
 from DFGNN.utils import sparse as dglsp
 
-from .GAT import GATConv_dgNN, GATConv_hyper, GATConv_softmax, GATConv_softmax_gm, GATConv_tiling
+from .GAT import (GATConv_dgNN, GATConv_hyper, GATConv_hyper_ablation, GATConv_hyper_recompute, GATConv_hyper_v2,
+                  GATConv_softmax, GATConv_softmax_gm, GATConv_tiling)
 from .GT import (SparseMHA_CSR, SparseMHA_CSR_GM, SparseMHA_forward_timing, SparseMHA_hyper, SparseMHA_softmax,
                  SparseMHA_softmax_gm, SparseMHA_tiling)
 
@@ -103,9 +104,10 @@ _GT_LAYERS = {
 _GAT_LAYERS = {
     "csr": GATConv_dgNN, "tiling": GATConv_tiling, "hyper": GATConv_hyper, "nofuse": GATConv_hyper,
     "softmax": GATConv_softmax, "softmax_gm": GATConv_softmax_gm,
+    "hyper_v2": GATConv_hyper_v2, "hyper_recompute": GATConv_hyper_recompute, "hyper_ablation": GATConv_hyper_ablation,
 }
 # formats of the reference that are baselines on NVIDIA-only libraries or paper experiments
-_OUT_OF_SCOPE = {"hybrid", "hyper_ablation", "pyg", "cugraph", "hyper_v2", "hyper_recompute", "subgraph"}
+_OUT_OF_SCOPE = {"hybrid", "pyg", "cugraph", "subgraph"}
 
 
 def _pick(table, args, conv):
@@ -135,7 +137,7 @@ def load_graphconv_layer(args):
 def load_prepfunc(args):
     if args.format in ("csr", "csr_gm", "tiling"):
         return preprocess_CSR
-    if args.format in ("hyper", "nofuse"):
+    if args.format in ("hyper", "nofuse", "hyper_ablation", "hyper_recompute", "hyper_v2"):
         return preprocess_Hyper
     if args.format in ("softmax", "softmax_gm"):
         return preprocess_softmax

@@ -1,8 +1,8 @@
 """GAT operator surface -- same names / signatures as the reference's DFGNN/operators/fused_gatconv.py.
 
 In scope: the hyper / softmax / softmax_gm / tiling inference functions and the training
-pair `GATConvFuse` / `FusedGATFunction`.  The hyper_v2 / hyper_recompute experiments are
-kept as names; their binding entry points raise NotImplementedError.
+pair `GATConvFuse` / `FusedGATFunction` and the hyper_v2 / hyper_recompute / hyper_ablation
+variants of the reference's comparison sweeps.
 """
 import fused_gatconv as fused_gat
 import torch
@@ -43,12 +43,12 @@ def GATConvFuse_inference(attn_row, attn_col, row_ptr, col_ind, negative_slope, 
 
 
 def GATConvFuse_inference_hyper_recompute(attn_row, attn_col, indptr, indices, negative_slope, in_feat):
-    """reference :39-44 (next)"""
+    """reference :39-44"""
     return fused_gat.gat_inference_hyper_recompute(attn_row, attn_col, indptr, indices, negative_slope, in_feat)
 
 
 def GATConvFuse_inference_hyper_v2(smem_consume, a_l, a_r, indptr, indices, negative_slope, in_feat):
-    """reference :47-52 (next)"""
+    """reference :47-52"""
     return fused_gat.gat_inference_hyper_v2(smem_consume, a_l, a_r, indptr, indices, negative_slope, in_feat)
 
 

@@ -198,6 +198,15 @@ int dfgnn_gat_tiling_fwd(int m, int nnz, int h, int f, const int *row_ptr, const
   return launch_gat_tiling_fwd(g, attn_row, attn_col, negative_slope, X, out, as_stream(stream));
 }
 
+int dfgnn_gat_attn_scores(int m, int h, int f, const float *a_l, const float *a_r, const float *X, float *attn_row,
+                          float *attn_col, dfgnn_stream_t stream) {
+  if (m < 0 || h < 0 || f < 0) return kErrBadArg;
+  if (m == 0 || h == 0) return 0;
+  if (h > 65535) return kErrUnsupported;
+  if (!a_l || !a_r || !X || !attn_row || !attn_col || f == 0) return kErrBadArg;
+  return launch_gat_attn_scores(m, h, f, a_l, a_r, X, attn_row, attn_col, as_stream(stream));
+}
+
 // The GAT training pair takes the matrix-core kernels when every range of the plan is dense and nothing is dropped.
 static bool gat_train_dense(Plan &p, const int *rows, const float *edge_mask, const int *plan, const int *plan_meta,
                             int m, int nnz, int f, bool v4) {

@@ -132,6 +132,8 @@ int launch_gat_tiling_fwd(const Csr &g, const float *attn_row, const float *attn
 int launch_gat_sddmm(const Csr &g, const float *attn_row, const float *attn_col, float slope, float *logits,
                      hipStream_t s);
 
+int launch_gat_attn_scores(int m, int h, int f, const float *a_l, const float *a_r, const float *X, float *attn_row,
+                           float *attn_col, hipStream_t s);
 // GAT training pair (gat_train.hip)
 int launch_gat_train_fwd(const Csr &g, const float *attn_row, const float *attn_col, float slope, const float *X,
                          const float *edge_mask, float attn_drop, float *edge_max, float *edge_sum, float *out,

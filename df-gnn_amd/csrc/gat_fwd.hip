@@ -90,6 +90,45 @@ __global__ __launch_bounds__(kBlock) void gat_sddmm_kernel(Csr g, const float *_
   }
 }
 
+// attn_row[i, hd] = <a_l[hd, :], X[i, hd, :]>, attn_col[i, hd] = <a_r[hd, :], X[i, hd, :]>: X is read once for both.
+// A lane group per (node, head).  replaces fused_gat_dot_attn_weight (fused_gatconv_hyper_v2.cu:212-249), the first
+// kernel of the 'hyper_v2' variant.
+template <class C>
+__global__ __launch_bounds__(kBlock) void gat_attn_scores_kernel(int m, int h, int f, const float *__restrict__ a_l,
+                                                                 const float *__restrict__ a_r,
+                                                                 const float *__restrict__ X,
+                                                                 float *__restrict__ attn_row,
+                                                                 float *__restrict__ attn_col) {
+  const int gl = threadIdx.x % C::G;
+  const long stride = (long)gridDim.x * (kBlock / C::G);
+  Frag<C> al, ar;
+  const int head = blockIdx.y;
+  frag_load<C>(al, a_l + (size_t)head * f, f, gl);
+  frag_load<C>(ar, a_r + (size_t)head * f, f, gl);
+  for (long i = (long)blockIdx.x * (kBlock / C::G) + threadIdx.x / C::G; i < m; i += stride) {
+    Frag<C> x;
+    frag_load<C>(x, X + ((size_t)i * h + head) * f, f, gl);
+    const float r = lanes_sum<C::G>(frag_dot<C>(al, x)), c = lanes_sum<C::G>(frag_dot<C>(ar, x));
+    if (gl == 0) {
+      attn_row[(size_t)i * h + head] = r;
+      attn_col[(size_t)i * h + head] = c;
+    }
+  }
+}
+
+int launch_gat_attn_scores(int m, int h, int f, const float *a_l, const float *a_r, const float *X, float *attn_row,
+                           float *attn_col, hipStream_t s) {
+  const bool v4 = (f % 4 == 0) && aligned16(X) && aligned16(a_l) && aligned16(a_r);
+  return dispatch_cfg(f, v4, [&](auto cfg) {
+    using C = decltype(cfg);
+    const long per = kBlock / C::G;
+    long blocks = ((long)m + per - 1) / per;
+    if (blocks > 65536) blocks = 65536;
+    gat_attn_scores_kernel<C><<<dim3((unsigned)blocks, h), kBlock, 0, s>>>(m, h, f, a_l, a_r, X, attn_row, attn_col);
+    return launch_status();
+  });
+}
+
 int launch_gat_hyper_fwd(const Csr &g, const float *attn_row, const float *attn_col, float slope,
                          const float *X, float *out, const int *chunks, int nchunks, hipStream_t s) {
   const dim3 grid(chunks ? nchunks : (g.m + kHyperRows - 1) / kHyperRows, g.h);

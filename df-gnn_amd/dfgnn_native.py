@@ -28,6 +28,7 @@ SIGNATURES = {
     "dfgnn_gat_softmax_fwd": [_i, _i, _i, _i] + [_vp] * 5 + [_f] + [_vp] * 4,
     "dfgnn_gat_softmax_gm_fwd": [_i, _i, _i, _i] + [_vp] * 5 + [_f] + [_vp] * 4,
     "dfgnn_gat_tiling_fwd": [_i, _i, _i, _i] + [_vp] * 4 + [_f] + [_vp] * 3,
+    "dfgnn_gat_attn_scores": [_i, _i, _i] + [_vp] * 6,
     "dfgnn_gat_fwd_train": [_i, _i, _i, _i] + [_vp] * 5 + [_f] + [_vp] * 2 + [_f] + [_vp] * 6,
     "dfgnn_gat_bwd": [_i, _i, _i, _i] + [_vp] * 8 + [_f] + [_vp] * 4 + [_f] + [_vp] * 8,
 }

@@ -4,8 +4,8 @@ MI355X HIP library through its C ABI (include/dfgnn.h).  See fused_gtconv.py for
 
 In scope: the four inference entry points of the hyper / softmax /
 softmax_gm / tiling variants, and the training pair gat_forward / gat_backward
-behind FusedGATFunction.  The experimental hyper_v2 / hyper_recompute / tb entry points are "next"
- and raise NotImplementedError rather than pretending.
+behind FusedGATFunction and (8f rank 3) the hyper_v2 / hyper_recompute entry points of the reference's comparison
+sweeps.  The tile-scheduler experiment gat_forward_tb raises NotImplementedError rather than pretending.
 """
 import torch
 
@@ -99,11 +99,49 @@ def gat_inference(attn_row, attn_col, row_ptr, col_ind, negative_slope, in_feat)
     return gat_inference_tiling(attn_row, attn_col, row_ptr, col_ind, negative_slope, in_feat)
 
 
+def gat_inference_hyper_recompute(attn_row, attn_col, indptr, indices, negative_slope, in_feat):
+    """fused_gatconv.cpp:124-142 -> Tensor.  CSR only; the reference's kernel recomputes the logits instead of keeping
+    them in shared memory (fused_gatconv_hyper_recompute.cu) -- which is what the online-softmax tiling kernel does for
+    every row, so it serves this entry point (same function, no degree limit, any f; the reference exit(0)s unless
+    f % 128 == 0)."""
+    return gat_inference_tiling(attn_row, attn_col, indptr, indices, negative_slope, in_feat)
+
+
+def gat_inference_hyper_v2(smem_consume, a_l, a_r, indptr, indices, negative_slope, in_feat):
+    """fused_gatconv.cpp:148-158 -> Tensor.  a_l, a_r: the layer's attention vectors, [heads, f] (a leading 1 is
+    accepted, as the layers pass them).  Two kernels like the reference's (fused_gatconv_hyper_v2.cu:251-281): the
+    per-node scores <a_l, X_i>, <a_r, X_i> in one pass over X, then the fused 'hyper' convolution -- with a block plan
+    and the COO rows derived from indptr (this entry point takes CSR only), else the CSR tiling kernel.
+    The reference reads a_l / a_r as contiguous [heads, f] whatever their strides (the layers hand it a transposed
+    view: only right for heads == 1); here they are made contiguous first."""
+    check_device(a_l=a_l, a_r=a_r, in_feat=in_feat)
+    check_dtype(torch.float32, a_l=a_l, a_r=a_r, in_feat=in_feat)
+    if in_feat.dim() != 3:
+        raise RuntimeError(f"in_feat must have shape [nodes, heads, feat], got {tuple(in_feat.shape)}")
+    m, h, f = in_feat.shape
+    a_l, a_r = a_l.reshape(-1, a_l.shape[-1]).contiguous(), a_r.reshape(-1, a_r.shape[-1]).contiguous()
+    if tuple(a_l.shape) != (h, f) or tuple(a_r.shape) != (h, f):
+        raise RuntimeError(f"a_l / a_r must have shape ({h}, {f}), got {tuple(a_l.shape)} / {tuple(a_r.shape)}")
+    check_contiguous(in_feat=in_feat)
+    dev = in_feat.device
+    with torch.cuda.device(dev):
+        attn_row = torch.empty((m, h), dtype=torch.float32, device=dev)
+        attn_col = torch.empty((m, h), dtype=torch.float32, device=dev)
+        _n.check(_n.lib().dfgnn_gat_attn_scores(m, h, f, ptr(a_l), ptr(a_r), ptr(in_feat), ptr(attn_row), ptr(attn_col),
+                                                stream_ptr(dev)), "gat_inference_hyper_v2 (scores)")
+    _check(attn_row, attn_col, indptr, indices, None, in_feat)
+    plan, _, _ = get_plan(indptr, indices, f, USE_BLOCK_PLAN)
+    if plan is not None:
+        return gat_inference_hyper(smem_consume, attn_row, attn_col, indptr, indices, get_rows(indptr, indices.size(0)),
+                                   negative_slope, in_feat)
+    return gat_inference_tiling(attn_row, attn_col, indptr, indices, negative_slope, in_feat)
+
+
 def _next(name):
     def fn(*args, **kwargs):
         raise NotImplementedError(
-            f"fused_gatconv.{name} is outside this build's hot-path scope (SURVEY.md 8f 'next'); "
-            "use the hyper / softmax / softmax_gm / tiling inference entry points")
+            f"fused_gatconv.{name} is outside this build's hot-path scope (a tile-scheduler experiment of the "
+            "reference); use gat_forward / the hyper / softmax / softmax_gm / tiling entry points")
     fn.__name__ = name
     return fn
 
@@ -190,5 +228,3 @@ def gat_backward(negative_slope, attn_drop, row_ptr, col_ind, col_ptr, row_ind, 
 
 
 gat_forward_tb = _next("gat_forward_tb")
-gat_inference_hyper_v2 = _next("gat_inference_hyper_v2")
-gat_inference_hyper_recompute = _next("gat_inference_hyper_recompute")

@@ -167,6 +167,13 @@ int dfgnn_gat_tiling_fwd(int m, int nnz, int h, int f, const int *row_ptr, const
                          const float *attn_row, const float *attn_col, float negative_slope,
                          const float *X, float *out, dfgnn_stream_t stream);
 
+/* First kernel of the reference's 'hyper_v2' variant (gat_inference_hyper_v2, fused_gatconv.cpp:148-158;
+ * fused_gat_dot_attn_weight, fused_gatconv_hyper_v2.cu:212-249): the per-node attention scores from the layer's
+ * attention vectors a_l, a_r fp32[h, f]:  attn_row[i, hd] = <a_l[hd], X[i, hd]>,  attn_col[i, hd] = <a_r[hd], X[i, hd]>.
+ * X is read once for both.  The second kernel of 'hyper_v2' is dfgnn_gat_hyper_fwd / dfgnn_gat_tiling_fwd. */
+int dfgnn_gat_attn_scores(int m, int h, int f, const float *a_l, const float *a_r, const float *X,
+                          float *attn_row, float *attn_col, dfgnn_stream_t stream);
+
 /* ---- GAT training pair (FusedGATFunction, DFGNN/operators/fused_gatconv.py:95-176) --------------------
  * edge_max, edge_sum fp32[m, h]: per-row maximum of the LeakyReLU logits (-1e38 for an empty row) and
  *   sum_e exp(s_e - max); the backward recomputes P_e from them, as the reference does.

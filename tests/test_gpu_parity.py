@@ -221,9 +221,9 @@ def test_layers_fused_vs_baseline():
     g = S.pattern_like(batch_size=16, seed=3).to(DEV)
     x = torch.randn(g.num_nodes(), 64, device=DEV)
     for conv in ("gt", "gat"):
-        for fmt in ("hyper", "softmax", "softmax_gm", "tiling", "csr"):
-            if conv == "gat" and fmt == "csr_gm":
-                continue
+        for fmt in ("hyper", "softmax", "softmax_gm", "tiling", "csr", "hyper_ablation", "hyper_v2", "hyper_recompute"):
+            if conv == "gt" and fmt in ("hyper_v2", "hyper_recompute"):
+                continue                                    # GAT-only variants (reference layers/util.py:403-406)
             args = argparse.Namespace(conv=conv, format=fmt, dim=64, heads=1)
             layer = load_graphconv_layer(args).to(DEV).eval()
             with torch.no_grad():
@@ -773,3 +773,37 @@ def test_hipgraph_capture_of_a_training_step(shape):
     for a, b in zip(step(), again):
         assert torch.equal(a, b)
     assert not torch.equal(again[0], eager[0])
+
+
+@pytest.mark.parametrize("h,f,batched", [(1, 128, True), (4, 32, True), (2, 20, False), (3, 7, False)])
+def test_gat_hyper_v2_and_recompute(oracle_mod, h, f, batched):
+    """gat_inference_hyper_v2 (scores kernel + conv, multi-head a_l / a_r handed over as the
+    layers do: a transposed view) and gat_inference_hyper_recompute against the oracle."""
+    import fused_gatconv as gat
+    from DFGNN.layers.util import preprocess_Hyper
+    from DFGNN.utils import Graph
+    from DFGNN.utils import synthetic as S
+    rng = np.random.default_rng(h * 100 + f)
+    if batched:
+        g = S.pattern_like(batch_size=12, seed=5).to(DEV)
+    else:
+        n = 300
+        g = Graph(rng.integers(0, n, 4000), rng.integers(0, n, 4000), n).to(DEV)
+    indptr, indices, rows, val, smem = preprocess_Hyper(g)
+    m = g.num_nodes()
+    X = torch.randn(m, h, f, device=DEV)
+    a_l = torch.randn(1, f, h, device=DEV).transpose(1, 2)         # [1, h, f] view, not contiguous for h > 1
+    a_r = torch.randn(1, f, h, device=DEV).transpose(1, 2)
+    ar, ac = (a_l * X).sum(-1), (a_r * X).sum(-1)
+    n_ = lambda t: t.cpu().numpy()  # noqa: E731
+    want = oracle_mod.gat_forward(n_(indptr), n_(indices), n_(ar), n_(ac), 0.2, n_(X))
+    _close(gat.gat_inference_hyper_v2(smem, a_l, a_r, indptr, indices, 0.2, X), want, "hyper_v2")
+    _close(gat.gat_inference_hyper_recompute(ar, ac, indptr, indices, 0.2, X), want, "hyper_recompute")
+    # the scores kernel on its own, against float64
+    L = __import__("dfgnn_native").lib()
+    sr, sc = torch.empty(m, h, device=DEV), torch.empty(m, h, device=DEV)
+    al, arr = a_l.reshape(h, f).contiguous(), a_r.reshape(h, f).contiguous()
+    assert L.dfgnn_gat_attn_scores(m, h, f, al.data_ptr(), arr.data_ptr(), X.data_ptr(), sr.data_ptr(), sc.data_ptr(),
+                                   torch.cuda.current_stream().cuda_stream) == 0
+    _close(sr, n_((al.double() * X.double()).sum(-1)), "attn_row scores")
+    _close(sc, n_((arr.double() * X.double()).sum(-1)), "attn_col scores")

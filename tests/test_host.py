@@ -80,8 +80,12 @@ def test_binding_rejects_cpu_tensors_and_bad_dtypes():
         fused_gatconv.gat_forward(a, a, ip, idx, 0.2, q, 0.0)
     with pytest.raises(RuntimeError, match="must be on CUDA"):
         fused_gatconv.gat_backward(0.2, 0.0, ip, idx, ip, idx, idx, a, a, a, q, a, a, q)
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(RuntimeError, match="must be on CUDA"):
         fused_gatconv.gat_inference_hyper_v2(1024, a, a, ip, idx, 0.2, q)
+    with pytest.raises(RuntimeError, match="must be on CUDA"):
+        fused_gatconv.gat_inference_hyper_recompute(a, a, ip, idx, 0.2, q)
+    with pytest.raises(NotImplementedError):                        # the tile-scheduler experiment stays out of scope
+        fused_gatconv.gat_forward_tb(a, a, ip, idx, 0.2, q, None)
 
 
 def _args(conv, fmt, dim, heads):
@@ -90,7 +94,8 @@ def _args(conv, fmt, dim, heads):
 
 @pytest.mark.parametrize("conv,fmt", [("gt", "hyper"), ("gt", "softmax"), ("gt", "tiling"), ("gt", "softmax_gm"),
                                       ("gat", "hyper"), ("gat", "softmax"), ("gat", "tiling"),
-                                      ("gat", "softmax_gm")])
+                                      ("gat", "softmax_gm"), ("gat", "hyper_v2"), ("gat", "hyper_recompute"),
+                                      ("gat", "hyper_ablation"), ("gt", "hyper_ablation")])
 def test_layer_baseline_branch_matches_oracle(oracle_mod, conv, fmt):
     """fuse=False branch (torch restatement of dgl.sparse) at the layer boundary vs the oracle at the
     operator boundary, through the layer's own layout transforms."""
