@@ -100,6 +100,7 @@ _GT_LAYERS = {
     "csr": SparseMHA_CSR, "csr_gm": SparseMHA_CSR_GM, "tiling": SparseMHA_tiling, "hyper": SparseMHA_hyper,
     "nofuse": SparseMHA_hyper, "softmax": SparseMHA_softmax, "softmax_gm": SparseMHA_softmax_gm,
     "forward": SparseMHA_forward_timing,
+    "hyper_ablation": SparseMHA_hyper,  # reference :385-386 (ablation entry; served by the production kernel)
 }
 _GAT_LAYERS = {
     "csr": GATConv_dgNN, "tiling": GATConv_tiling, "hyper": GATConv_hyper, "nofuse": GATConv_hyper,
