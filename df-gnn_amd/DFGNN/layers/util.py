@@ -15,6 +15,8 @@ import torch
 
 from DFGNN.utils import sparse as dglsp
 
+from .AGNN import (AGNNConv_csr, AGNNConv_csr_gm, AGNNConv_hyper, AGNNConv_softmax, AGNNConv_softmax_gm,
+                   AGNNConv_tiling)
 from .GAT import (GATConv_dgNN, GATConv_hyper, GATConv_hyper_ablation, GATConv_hyper_recompute, GATConv_hyper_v2,
                   GATConv_softmax, GATConv_softmax_gm, GATConv_tiling)
 from .GT import (SparseMHA_CSR, SparseMHA_CSR_GM, SparseMHA_forward_timing, SparseMHA_hyper, SparseMHA_softmax,
@@ -107,6 +109,10 @@ _GAT_LAYERS = {
     "softmax": GATConv_softmax, "softmax_gm": GATConv_softmax_gm,
     "hyper_v2": GATConv_hyper_v2, "hyper_recompute": GATConv_hyper_recompute, "hyper_ablation": GATConv_hyper_ablation,
 }
+_AGNN_LAYERS = {  # reference :424-442
+    "hyper": AGNNConv_hyper, "csr": AGNNConv_csr, "softmax": AGNNConv_softmax, "csr_gm": AGNNConv_csr_gm,
+    "tiling": AGNNConv_tiling, "softmax_gm": AGNNConv_softmax_gm,
+}
 # formats of the reference that are baselines on NVIDIA-only libraries or paper experiments
 _OUT_OF_SCOPE = {"hybrid", "pyg", "cugraph", "subgraph"}
 
@@ -127,9 +133,15 @@ def load_layer_GAT(args):
     return _pick(_GAT_LAYERS, args, "GATconv")
 
 
+def load_layer_AGNN(args):
+    return _pick(_AGNN_LAYERS, args, "AGNNconv")
+
+
 def load_graphconv_layer(args):
     if args.conv == "gat":
         return load_layer_GAT(args)
+    if args.conv == "agnn":
+        return load_layer_AGNN(args)
     if args.conv == "gt":
         return load_layer_GT(args)
     raise ValueError(f"unknown graph conv {args.conv}")

@@ -95,12 +95,15 @@ def _args(conv, fmt, dim, heads):
 @pytest.mark.parametrize("conv,fmt", [("gt", "hyper"), ("gt", "softmax"), ("gt", "tiling"), ("gt", "softmax_gm"),
                                       ("gat", "hyper"), ("gat", "softmax"), ("gat", "tiling"),
                                       ("gat", "softmax_gm"), ("gat", "hyper_v2"), ("gat", "hyper_recompute"),
-                                      ("gat", "hyper_ablation"), ("gt", "hyper_ablation")])
+                                      ("gat", "hyper_ablation"), ("gt", "hyper_ablation"), ("agnn", "hyper"),
+                                      ("agnn", "csr"), ("agnn", "softmax_gm"), ("agnn", "csr_gm")])
 def test_layer_baseline_branch_matches_oracle(oracle_mod, conv, fmt):
     """fuse=False branch (torch restatement of dgl.sparse) at the layer boundary vs the oracle at the
     operator boundary, through the layer's own layout transforms."""
     torch.manual_seed(0)
     dim, heads = 32, 4
+    if conv == "agnn":
+        heads = 1  # the reference's AGNN projects to out_size, not out_size * heads (agnn_layer.py:12): single head
     layer = load_graphconv_layer(_args(conv, fmt, dim, heads)).eval()
     assert load_prepfunc(_args(conv, fmt, dim, heads)) is not None
     g = S.pattern_like(batch_size=3, seed=5)
@@ -110,7 +113,14 @@ def test_layer_baseline_branch_matches_oracle(oracle_mod, conv, fmt):
     with torch.no_grad():
         out, ms = layer(A, x, fuse=False)
     row_ptr, col_ind, val, _ = preprocess_CSR(g)
-    if conv == "gt":
+    if conv == "agnn":
+        Hb = layer.proj(x).view(-1, layer.out_size, heads).detach()          # baseline layout [N, out, heads]
+        Ho = Hb.transpose(1, 2).contiguous()                                 # operator layout [N, heads, out]
+        Hn = torch.nn.functional.normalize(Ho, p=2, dim=-1)
+        ref = oracle_mod.gt_forward(row_ptr.numpy(), col_ind.numpy(), val.numpy(), Hn.numpy(), Hn.numpy(), Ho.numpy())
+        ref = torch.from_numpy(ref).reshape(n, -1)
+        assert out.shape == (n, dim * heads)
+    elif conv == "gt":
         q, k, v = layer.prep_qkv(x)
         q, k, v = (t.transpose(1, 2).contiguous().detach().numpy() for t in (q, k, v))
         ref = oracle_mod.gt_forward(row_ptr.numpy(), col_ind.numpy(), val.numpy(), q, k, v)
