@@ -837,3 +837,19 @@ def test_agnn_training_layer_grads_match_autograd_baseline():
     for a, b, what in zip(grads[0], grads[1], ("out", "proj.weight.grad", "proj.bias.grad")):
         scale = float(a.abs().max())
         assert torch.allclose(a, b, atol=1e-3 * max(1.0, scale), rtol=1e-3), what
+
+
+def test_multilayer_training_fused_vs_baseline():
+    """tools/train_stack.py at toy size: a 3-layer residual stack trained with Adam on fresh batches, fused operators
+    vs the non-fused torch branch -- the losses must track each other (same init, same data)."""
+    import argparse
+    import importlib.util
+    from conftest import ROOT
+    spec = importlib.util.spec_from_file_location("train_stack", f"{ROOT}/tools/train_stack.py")
+    ts = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ts)
+    args = argparse.Namespace(layers=3, batch_size=6, dim=64, steps=5, warmup=1, batches=2)
+    fused = ts.run(args, True, torch.device(DEV))
+    base = ts.run(args, False, torch.device(DEV))
+    assert abs(fused["final_loss"] - base["final_loss"]) <= 1e-3 * max(1.0, abs(base["final_loss"]))
+    assert fused["preprocess_ms"] > 0 and fused["layer_edges_per_s"] > 0

@@ -1,0 +1,101 @@
+#!/usr/bin/env python3
+"""The operator in its real calling pattern (reference: an 8-layer stack trained with Adam,
+DFGNN/script/train/train_batch_graph_timing.py:32-53, 146-196): fresh PATTERN-like batches every step, preprocessing
+(COO -> CSR / CSC + block plan) paid per batch, L SparseMHA_forward layers sharing the batch structure, MSE loss,
+Adam.  Prints one JSON line per mode (fused operators vs the non-fused torch branch) with the per-step time split the
+reference reports (preprocess / forward / backward+update) and the loss after the last step.
+usage: python3 tools/train_stack.py [--layers 8] [--batch-size 256] [--dim 128] [--steps 12] [--batches 4]"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "df-gnn_amd")):
+    sys.path.insert(0, p)
+import torch  # noqa: E402
+from torch import nn  # noqa: E402
+
+from DFGNN.layers import SparseMHA_forward, preprocess_Hyper_fw_bw  # noqa: E402
+from DFGNN.utils import synthetic as S  # noqa: E402
+
+
+class Stack(nn.Module):
+    def __init__(self, dim, layers):
+        super().__init__()
+        self.inproj = nn.Linear(dim, dim)
+        self.layers = nn.ModuleList(SparseMHA_forward(dim, dim, 1) for _ in range(layers))
+        self.out = nn.Linear(dim, 1)
+
+    def forward(self, params, x, fuse):
+        h = self.inproj(x)
+        for layer in self.layers:
+            h = h + layer(params, h, fuse)          # residual, as the reference's GTModel does around its MHA blocks
+        return self.out(h)
+
+
+def run(args, fuse, dev):
+    torch.manual_seed(0)
+    model = Stack(args.dim, args.layers).to(dev).train()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    graphs = [S.pattern_like(batch_size=args.batch_size, seed=10 + b).to(dev) for b in range(args.batches)]
+    feats = [torch.randn(g.num_nodes(), args.dim, device=dev, generator=torch.Generator(dev).manual_seed(b))
+             for b, g in enumerate(graphs)]
+    target = [torch.randn(g.num_nodes(), 1, device=dev, generator=torch.Generator(dev).manual_seed(100 + b))
+              for b, g in enumerate(graphs)]
+    t_prep = t_fwd = t_bwd = 0.0
+    loss_v, edges = None, 0
+    for step in range(args.warmup + args.steps):
+        b = step % args.batches
+        g = graphs[b]
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        params = preprocess_Hyper_fw_bw(g, fused=True)      # fresh tensors: the block plan is rebuilt as well
+        if not fuse:
+            params = (params[0],) + (None,) * 8
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        loss = nn.functional.mse_loss(model(params, feats[b], fuse), target[b])
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+        torch.cuda.synchronize()
+        t3 = time.perf_counter()
+        if step >= args.warmup:
+            t_prep += t1 - t0
+            t_fwd += t2 - t1
+            t_bwd += t3 - t2
+            edges += g.num_edges() * args.layers
+        loss_v = float(loss)
+    n = args.steps
+    return {"mode": "fused" if fuse else "torch baseline (fuse=False)", "layers": args.layers, "batch_size": args.batch_size,
+            "dim": args.dim, "steps": n, "preprocess_ms": t_prep / n * 1e3, "forward_ms": t_fwd / n * 1e3,
+            "backward_update_ms": t_bwd / n * 1e3, "step_ms": (t_prep + t_fwd + t_bwd) / n * 1e3,
+            "layer_edges_per_s": edges / (t_prep + t_fwd + t_bwd), "final_loss": loss_v}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--layers", type=int, default=8)
+    ap.add_argument("--batch-size", type=int, default=256)
+    ap.add_argument("--dim", type=int, default=128)
+    ap.add_argument("--steps", type=int, default=12)
+    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--batches", type=int, default=4)
+    ap.add_argument("--modes", default="fused,baseline")
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    res = []
+    for mode in args.modes.split(","):
+        res.append(run(args, mode == "fused", dev))
+        print(json.dumps(res[-1]), flush=True)
+    if len(res) == 2:
+        print(json.dumps({"speedup_step": res[1]["step_ms"] / res[0]["step_ms"],
+                          "loss_abs_diff": abs(res[0]["final_loss"] - res[1]["final_loss"])}), flush=True)
+
+
+if __name__ == "__main__":
+    main()
