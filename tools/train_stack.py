@@ -74,7 +74,12 @@ def run(args, fuse, dev):
     return {"mode": "fused" if fuse else "torch baseline (fuse=False)", "layers": args.layers, "batch_size": args.batch_size,
             "dim": args.dim, "steps": n, "preprocess_ms": t_prep / n * 1e3, "forward_ms": t_fwd / n * 1e3,
             "backward_update_ms": t_bwd / n * 1e3, "step_ms": (t_prep + t_fwd + t_bwd) / n * 1e3,
-            "layer_edges_per_s": edges / (t_prep + t_fwd + t_bwd), "final_loss": loss_v}
+            "layer_edges_per_s": edges / (t_prep + t_fwd + t_bwd), "final_loss": loss_v,
+            # after training: L1 norm of the attention projections' total update direction (sensitive to the operator's
+            # gradients, unlike the loss, which the random targets dominate)
+            "qkv_weight_l1": float(sum(p.detach().abs().sum() for n_, p in model.named_parameters() if "_proj" in n_)),
+            "qkv_weights": torch.cat([p.detach().flatten() for n_, p in model.named_parameters() if "q_proj.weight" in n_])
+            if args.layers <= 3 else None}
 
 
 def main():
@@ -91,10 +96,13 @@ def main():
     res = []
     for mode in args.modes.split(","):
         res.append(run(args, mode == "fused", dev))
+        res[-1].pop("qkv_weights")
         print(json.dumps(res[-1]), flush=True)
     if len(res) == 2:
         print(json.dumps({"speedup_step": res[1]["step_ms"] / res[0]["step_ms"],
-                          "loss_abs_diff": abs(res[0]["final_loss"] - res[1]["final_loss"])}), flush=True)
+                          "loss_abs_diff": abs(res[0]["final_loss"] - res[1]["final_loss"]),
+                          "qkv_weight_l1_rel_diff": abs(res[0]["qkv_weight_l1"] - res[1]["qkv_weight_l1"])
+                          / res[1]["qkv_weight_l1"]}), flush=True)
 
 
 if __name__ == "__main__":
