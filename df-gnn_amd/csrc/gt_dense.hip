@@ -631,10 +631,10 @@ __device__ __forceinline__ void dense_bwd_body(float *lds, const Csr &g, int n0,
         image_prefetch(Kb, 0, n);  // next image: K rows 0..
       } else if constexpr (CW * NBLK > RB) {
         // GAT: the next row block's dO rows are all that is left to fetch (its edges are fetched after dS: they would
-        // not fit next to dP / P).  Unconditional -- the last row block re-reads its own rows (L2 hits, unused): a
-        // prefetch under a condition turns the staging registers into loop-carried values and spills them.
-        const bool more = i0 + RB < n;
-        image_prefetch(dOb, more ? i0 + RB : i0, more ? min(n, i0 + 2 * RB) : i0 + ni);
+        // not fit next to dP / P).  Unconditional -- after the last row block it re-reads one row (unused): a prefetch
+        // under a condition turns the staging registers into loop-carried values and spills them.
+        const bool more = i0 + RB < n;  // (last block: every load is clamped onto row i0 -- cache hits, no HBM traffic)
+        image_prefetch(dOb, more ? i0 + RB : i0, more ? min(n, i0 + 2 * RB) : i0 + 1);
       }
       lds_barrier();
       if (row_wave) {
