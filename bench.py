@@ -270,7 +270,7 @@ def main():
 
     # ---- CPU baseline: the oracle's fp32 OpenMP build on a bounded sample of the same workload
     cpu = None
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:  # (the contract: rank 0 at N = 1 only)
         import oracle
         oracle.build()
         ng = min(args.cpu_sample_graphs, args.batch_size)
