@@ -98,10 +98,11 @@ int launch_gt_dense_bwd(const Csr &g, const Plan &p, const float *Q, const float
 // edge_max / edge_sum (nullable): row statistics for the GAT training pair
 int launch_gat_dense_fwd(const Csr &g, const Plan &p, const float *attn_row, const float *attn_col, float slope,
                          const float *X, float *out, hipStream_t s, float *edge_max = nullptr,
-                         float *edge_sum = nullptr);
+                         float *edge_sum = nullptr, const float *edge_mask = nullptr, float attn_drop = 0.f);
 int launch_gat_dense_bwd(const Csr &g, const Plan &p, const float *attn_row, const float *attn_col, float slope,
                          const float *X, const float *edge_max, const float *edge_sum, const float *grad_out,
-                         float *grad_feat, float *grad_row, float *grad_col, hipStream_t s);
+                         float *grad_feat, float *grad_row, float *grad_col, hipStream_t s,
+                         const float *edge_mask = nullptr, float attn_drop = 0.f);
 int launch_gt_tiling_fwd(const Csr &g, const float *Q, const float *K, const float *V, float *out,
                          hipStream_t s);
 int launch_gt_sddmm(const Csr &g, const float *Q, const float *K, float *logits, hipStream_t s);

@@ -45,13 +45,21 @@ __device__ unsigned long long *dfgnn_dense_stamps = nullptr;  // [wg][16] phase 
 // (2, 128, 2) up to 255.
 // GAT = true: the logits are LeakyReLU(attn_row[i] + attn_col[j]) instead of <Q_i, K_j> (Q = attn_row [m, h],
 // K = attn_col [m, h], V = X): no K image and no first product, everything else is shared.
+// Attention dropout of the GAT training pair (gat_train.hip: GatDrop): keep edge e of head hd iff
+// mask[e * h + hd] > drop, kept attention scaled by `scale` = 1 / (1 - drop).  mask == NULL: no dropout.
+struct DenseDrop {
+  const float *mask = nullptr;
+  float drop = 0.f, scale = 1.f;
+};
+
 template <int F, bool WRITE_ATTN, int NS, int CR, int NCH, bool GAT = false>
 __device__ __forceinline__ void dense_fwd_body(float *lds, int lds_bytes, const Csr &g, int n0, int n, int e0, int ne,
                                                int head, const float *__restrict__ Q, const float *__restrict__ K,
                                                const float *__restrict__ V, float *__restrict__ attn_edge,
                                                float *__restrict__ out, float slope = 0.f,
                                                float *__restrict__ stat_max = nullptr,
-                                               float *__restrict__ stat_sum = nullptr) {
+                                               float *__restrict__ stat_sum = nullptr,
+                                               const DenseDrop drop = DenseDrop{}) {
   using D = DenseCfg<F>;
   constexpr int RS = D::RS, KT = D::KT, FT = D::FT, TPC = CR / 16, NT = TPC * NCH;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
@@ -83,6 +91,10 @@ __device__ __forceinline__ void dense_fwd_body(float *lds, int lds_bytes, const 
       if (tid < n) ac_mine = K[(size_t)(n0 + tid) * g.h + head];
   }
   int pre_i[kDensePre], pre_j[kDensePre];
+  float pre_m[GAT ? kDensePre : 1];  // GAT with dropout: the edges' uniform randoms
+  const float *mask_h = nullptr;     // ... of this head, edge e at mask_h[(e0 + e) * h]
+  if constexpr (GAT)
+    if (drop.mask) mask_h = drop.mask + (size_t)e0 * g.h + head;
   {
     const int tid = opaque_tid();
 #pragma unroll
@@ -90,6 +102,7 @@ __device__ __forceinline__ void dense_fwd_body(float *lds, int lds_bytes, const 
       const unsigned e = (unsigned)min(tid + k * kDenseThreads, ne - 1);  // clamped: plain loads
       pre_i[k] = ld32(g.rows + e0, e);
       pre_j[k] = ld32(g.col_ind + e0, e);
+      if constexpr (GAT) pre_m[k] = mask_h ? mask_h[(size_t)e * g.h] : 1.f;
     }
   }
   DenseStageRegs<F, CR> st;
@@ -120,19 +133,22 @@ __device__ __forceinline__ void dense_fwd_body(float *lds, int lds_bytes, const 
   }
   lds_barrier();
   {  // byte map: position of every edge within its row (the plan guarantees distinct columns and rows < 255 long);
-     // the edge loads were issued first, so this runs while the K rows are still on their way
+     // the edge loads were issued first, so this runs while the K rows are still on their way.
+     // GAT with dropout (positions are not needed there): 0 = kept edge, 1 = dropped edge.
     const int tid = opaque_tid();
 #pragma unroll
     for (int k = 0; k < kDensePre; ++k) {
       const int e = tid + k * kDenseThreads;
       if (e < ne) {
         const int i = pre_i[k] - n0, j = pre_j[k] - n0;
-        map[i * MS + j] = (unsigned char)(e - rp[i]);
+        if (GAT && mask_h) map[i * MS + j] = (pre_m[GAT ? k : 0] > drop.drop) ? 0 : 1;
+        else map[i * MS + j] = (unsigned char)(e - rp[i]);
       }
     }
     for (int e = tid + kDensePre * kDenseThreads; e < ne; e += kDenseThreads) {
       const int i = g.rows[e0 + e] - n0, j = g.col_ind[e0 + e] - n0;
-      map[i * MS + j] = (unsigned char)(e - rp[i]);
+      if (GAT && mask_h) map[i * MS + j] = (mask_h[(size_t)e * g.h] > drop.drop) ? 0 : 1;
+      else map[i * MS + j] = (unsigned char)(e - rp[i]);
     }
   }
   dense_stage_store<F, CR>(st, ihi, ilo);
@@ -239,6 +255,16 @@ __device__ __forceinline__ void dense_fwd_body(float *lds, int lds_bytes, const 
           stat_max[(size_t)(n0 + i) * g.h + head] = (mx == -INFINITY) ? -1e38f : mx;
           stat_sum[(size_t)(n0 + i) * g.h + head] = sum;
         }
+        if (mask_h) {  // attention dropout after the softmax: the row sum counted every edge, the product skips
+          inv[s] *= drop.scale;  // the dropped ones
+#pragma unroll
+          for (int jt = 0; jt < NT; ++jt) {
+            const unsigned w = (jt < ntile) ? *reinterpret_cast<const unsigned *>(mrow + 16 * jt) : 0xFFFFFFFFu;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (((w >> (8 * r)) & 0xFFu) == 1u) S[s][jt][r] = 0.f;
+          }
+        }
       }
       if constexpr (WRITE_ATTN) {
         // attn_edge (CSR order): through LDS when the range's edge array fits (then the strip streams its own
@@ -340,19 +366,19 @@ __global__ __launch_bounds__(kDenseThreads) void gat_dense_fwd_kernel(Csr g, con
                                                                       const float *__restrict__ X,
                                                                       float *__restrict__ out, int lds_bytes,
                                                                       float *__restrict__ edge_max,
-                                                                      float *__restrict__ edge_sum) {
+                                                                      float *__restrict__ edge_sum, DenseDrop drop) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int n0 = fit[2 * blockIdx.x], n1 = fit[2 * blockIdx.x + 1] & kPlanRangeMask;
   const int n = n1 - n0, e0 = g.row_ptr[n0], ne = g.row_ptr[n1] - e0;
   if (n <= kDenseChunkRows)
     dense_fwd_body<F, false, 1, kDenseChunkRows, 1, true>(lds, lds_bytes, g, n0, n, e0, ne, blockIdx.y, attn_row, attn_col, X,
-                                                          nullptr, out, slope, edge_max, edge_sum);
+                                                          nullptr, out, slope, edge_max, edge_sum, drop);
   else if (n <= kDenseWideRows)
     dense_fwd_body<F, false, 2, kDenseWideRows, 1, true>(lds, lds_bytes, g, n0, n, e0, ne, blockIdx.y, attn_row, attn_col, X,
-                                                         nullptr, out, slope, edge_max, edge_sum);
+                                                         nullptr, out, slope, edge_max, edge_sum, drop);
   else
     dense_fwd_body<F, false, 2, kDenseChunkRows, 2, true>(lds, lds_bytes, g, n0, n, e0, ne, blockIdx.y, attn_row, attn_col, X,
-                                                          nullptr, out, slope, edge_max, edge_sum);
+                                                          nullptr, out, slope, edge_max, edge_sum, drop);
 }
 
 // =====================================================================================================================
@@ -380,6 +406,7 @@ struct GatBwdArgs {
   const float *edge_max, *edge_sum;  // [m, h] from the training forward
   float slope;
   float *grad_row, *grad_col;        // [m, h]
+  DenseDrop drop;                    // attention dropout: a dropped edge enters the P tile with a negative sign
 };
 
 template <int F, int CW, int NBLK, bool GAT = false>
@@ -393,7 +420,8 @@ __device__ __forceinline__ void dense_bwd_body(float *lds, const Csr &g, int n0,
   using G = DenseBwdGeom<CW, NBLK>;
   constexpr int RS = D::RS, KT = D::KT, FT = D::FT, RB = G::RB, RBP = G::RBP, U = G::U, TS = G::TS;
   constexpr int TB = 2 * TS;  // bf16 elements per interleaved tile row: hi at +0, lo at +TS
-  constexpr int PRE = kDensePre;  // edges fetched ahead per thread
+  // edges fetched ahead per thread (GAT: each edge also carries its dropout random, so fewer fit the registers)
+  constexpr int PRE = GAT ? 10 : kDensePre;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);  // = this wave's strip of a row block
   __bf16 *ihi = reinterpret_cast<__bf16 *>(lds), *ilo = ihi + (size_t)CW * RS;
   float *T = reinterpret_cast<float *>(ilo + (size_t)CW * RS);
@@ -454,11 +482,13 @@ __device__ __forceinline__ void dense_bwd_body(float *lds, const Csr &g, int n0,
       pi[k] = ld32(g.rows + ea0, e);
       pj[k] = ld32(g.col_ind + ea0, e);
       if constexpr (!GAT) pa[k] = ld32(attn_h + ea0, e);
+      else pa[k] = ga.drop.mask ? ga.drop.mask[((size_t)ea0 + e) * g.h + head] : 1.f;
     }
   };
   // GAT: P of edge (row i, column j of the range) from the staged scalars
-  auto gat_p = [&](int i, int j) {
-    return fast_exp(leaky_relu(arl[i] + acl[j], ga.slope) - mxl[i]) * ivl[i];
+  auto gat_p = [&](int i, int j, float rnd) {
+    const float pp = fast_exp(leaky_relu(arl[i] + acl[j], ga.slope) - mxl[i]) * ivl[i];
+    return (rnd > ga.drop.drop) ? pp : -pp;  // (no dropout: rnd = 1, drop = 0)
   };
   // Zero the tile, scatter P of tile (i0, j0) into it (fp32; edges [ea, eb) are the rows of the row block) and, if
   // `commit`, put the prefetched image into LDS.  `prefetched`: the first PRE edges per thread are in (pi, pj, pa).
@@ -472,7 +502,7 @@ __device__ __forceinline__ void dense_bwd_body(float *lds, const Csr &g, int n0,
       for (int k = 0; k < PRE; ++k) {
         const int j = pj[k] - n0 - j0;
         if (tid + k * kDenseThreads < eb - ea && j >= 0 && j < CW) {
-          if constexpr (GAT) T[(pi[k] - n0 - i0) * TS + j] = gat_p(pi[k] - n0, pj[k] - n0);
+          if constexpr (GAT) T[(pi[k] - n0 - i0) * TS + j] = gat_p(pi[k] - n0, pj[k] - n0, pa[k]);
           else T[(pi[k] - n0 - i0) * TS + j] = pa[k];
         }
       }
@@ -487,12 +517,13 @@ __device__ __forceinline__ void dense_bwd_body(float *lds, const Csr &g, int n0,
         bi[k] = ld32(g.rows + ea, e);
         bj[k] = ld32(g.col_ind + ea, e);
         if constexpr (!GAT) ba[k] = ld32(attn_h + ea, e);
+        else ba[k] = ga.drop.mask ? ga.drop.mask[((size_t)ea + e) * g.h + head] : 1.f;
       }
 #pragma unroll
       for (int k = 0; k < B; ++k) {
         const int j = bj[k] - n0 - j0;
         if (base + tid + k * kDenseThreads < eb - ea && j >= 0 && j < CW) {
-          if constexpr (GAT) T[(bi[k] - n0 - i0) * TS + j] = gat_p(bi[k] - n0, bj[k] - n0);
+          if constexpr (GAT) T[(bi[k] - n0 - i0) * TS + j] = gat_p(bi[k] - n0, bj[k] - n0, ba[k]);
           else T[(bi[k] - n0 - i0) * TS + j] = ba[k];
         }
       }
@@ -605,7 +636,16 @@ __device__ __forceinline__ void dense_bwd_body(float *lds, const Csr &g, int n0,
             Pr[jc][u] = f32x4{0.f, 0.f, 0.f, 0.f};
           }
         }
-        strip_to_tile(Pr[jc]);  // in place, own rows only
+        if constexpr (GAT) {  // the tile of the grad_feat product holds the dropped-out attention
+          f32x4 Pd[U];
+#pragma unroll
+          for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Pd[u][r] = Pr[jc][u][r] > 0.f ? Pr[jc][u][r] * ga.drop.scale : 0.f;
+          strip_to_tile(Pd);
+        } else {
+          strip_to_tile(Pr[jc]);  // in place, own rows only
+        }
       } else {  // (defined on every path: otherwise the arrays are carried around the row-block loop in registers)
 #pragma unroll
         for (int u = 0; u < U; ++u) Pr[jc][u] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -655,6 +695,17 @@ __device__ __forceinline__ void dense_bwd_body(float *lds, const Csr &g, int n0,
     }
     DFGNN_DSTAMP(1)
     if (row_wave) {
+      if constexpr (GAT) {  // g = keep dP / (1 - drop); P = |tile value|
+#pragma unroll
+        for (int jc = 0; jc < NBLK; ++jc)
+#pragma unroll
+          for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              dS[jc][u][r] = Pr[jc][u][r] > 0.f ? dS[jc][u][r] * ga.drop.scale : 0.f;
+              Pr[jc][u][r] = fabsf(Pr[jc][u][r]);
+            }
+      }
       float t = 0.f;
 #pragma unroll
       for (int jc = 0; jc < NBLK; ++jc)
@@ -841,24 +892,29 @@ int launch_gt_dense_fwd(const Csr &g, const Plan &p, const float *Q, const float
 }
 
 int launch_gat_dense_fwd(const Csr &g, const Plan &p, const float *attn_row, const float *attn_col, float slope,
-                         const float *X, float *out, hipStream_t s, float *edge_max, float *edge_sum) {
+                         const float *X, float *out, hipStream_t s, float *edge_max, float *edge_sum,
+                         const float *edge_mask, float attn_drop) {
   if (p.num_dense == 0) return 0;
   const dim3 grid(p.num_dense, g.h);
+  DenseDrop drop;
+  if (edge_mask) drop = DenseDrop{edge_mask, attn_drop, 1.f / (1.f - attn_drop)};
   return dispatch_dense(g.f, [&](auto fc) {
     constexpr int F = decltype(fc)::value;
     if (int rc = set_max_lds(gat_dense_fwd_kernel<F>)) return rc;
     gat_dense_fwd_kernel<F><<<grid, kDenseThreads, kLdsBytes, s>>>(g, p.fit(), attn_row, attn_col, slope, X, out, kLdsBytes,
-                                                                   edge_max, edge_sum);
+                                                                   edge_max, edge_sum, drop);
     return launch_status();
   });
 }
 
 int launch_gat_dense_bwd(const Csr &g, const Plan &p, const float *attn_row, const float *attn_col, float slope,
                          const float *X, const float *edge_max, const float *edge_sum, const float *grad_out,
-                         float *grad_feat, float *grad_row, float *grad_col, hipStream_t s) {
+                         float *grad_feat, float *grad_row, float *grad_col, hipStream_t s, const float *edge_mask,
+                         float attn_drop) {
   if (p.num_dense == 0) return 0;
   const dim3 grid(p.num_dense, g.h);
-  const GatBwdArgs ga{edge_max, edge_sum, slope, grad_row, grad_col};
+  GatBwdArgs ga{edge_max, edge_sum, slope, grad_row, grad_col, DenseDrop{}};
+  if (edge_mask) ga.drop = DenseDrop{edge_mask, attn_drop, 1.f / (1.f - attn_drop)};
   return dispatch_dense(g.f, [&](auto fc) {
     constexpr int F = decltype(fc)::value;
     if (int rc = set_max_lds(gat_dense_bwd_kernel<F>)) return rc;

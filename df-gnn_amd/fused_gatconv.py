@@ -147,10 +147,8 @@ def _next(name):
 
 
 def _train_plan(row_ptr, col_ind, f, attn_drop):
-    """(rows, plan, meta) for the training pair: the block plan and the COO row ids when the batch qualifies for the
-    matrix-core kernels (no dropout; the library checks that every range of the plan is dense), else Nones."""
-    if attn_drop > 0.0:
-        return None, None, None
+    """(rows, plan, meta) for the training pair: the block plan and the COO row ids when the batch may qualify for
+    the matrix-core kernels (the library checks that every range of the plan is dense), else Nones."""
     plan, meta, _ = get_plan(row_ptr, col_ind, f, USE_BLOCK_PLAN)
     if plan is None:
         return None, None, None

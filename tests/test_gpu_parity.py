@@ -618,8 +618,9 @@ def test_gat_train_pattern_like_batch(oracle_mod):
         print(drop, _gat_train_case(oracle_mod, case, drop))
 
 
+@pytest.mark.parametrize("attn_drop", [0.0, 0.4])
 @pytest.mark.parametrize("h,f", [(1, 128), (2, 64), (3, 32)])
-def test_gat_train_dense_every_geometry(oracle_mod, h, f):
+def test_gat_train_dense_every_geometry(oracle_mod, h, f, attn_drop):
     """GAT training pair on the matrix-core kernels (gat_dense_fwd_kernel with row statistics, gat_dense_bwd_kernel): a
     batch whose ranges are all dense and hit every geometry (1 strip, <= 128 nodes, 129-160 nodes with two row blocks,
     161-255 nodes with 2 x 2 tiles, isolated nodes, a directed graph whose last rows have in-edges only), against
@@ -651,15 +652,18 @@ def test_gat_train_dense_every_geometry(oracle_mod, h, f):
     m = g.num_nodes()
     ar, ac, X = S.gat_features(m, h, f, seed=8, device=DEV)
     dO = torch.randn(m, h, f, generator=torch.Generator().manual_seed(3)).to(DEV)
-    out, emax, esum, mask = gat.gat_forward(ar, ac, row_ptr, col_ind, 0.2, X, 0.0)
+    torch.manual_seed(77)
+    out, emax, esum, mask = gat.gat_forward(ar, ac, row_ptr, col_ind, 0.2, X, attn_drop)
     plan = row_ptr._dfgnn_plans[f]
     assert plan.num_dense == plan.num_fit > 0 and plan.num_spill == 0      # -> the library takes the dense kernels
     assert torch.equal(row_ptr._dfgnn_rows[1], rows)                        # derived COO rows == preprocess_Hyper's
-    gf, gr, gc = gat.gat_backward(0.2, 0.0, row_ptr, col_ind, col_ptr, row_ind, val_idx, emax, esum, mask, X, ar, ac, dO)
+    gf, gr, gc = gat.gat_backward(0.2, attn_drop, row_ptr, col_ind, col_ptr, row_ind, val_idx, emax, esum, mask, X, ar,
+                                  ac, dO)
     n_ = lambda t: t.cpu().numpy()  # noqa: E731
     args = (n_(row_ptr), n_(col_ind), n_(ar), n_(ac), 0.2, n_(X))
-    w_out, w_max, w_sum = oracle_mod.gat_train_forward(*args)
-    w_gf, w_gr, w_gc = oracle_mod.gat_backward(*args, n_(dO))
+    mask_np = n_(mask) if attn_drop > 0 else None
+    w_out, w_max, w_sum = oracle_mod.gat_train_forward(*args, mask_np, attn_drop)
+    w_gf, w_gr, w_gc = oracle_mod.gat_backward(*args, n_(dO), mask_np, attn_drop)
     deg = np.diff(n_(row_ptr))
     has = torch.from_numpy(deg > 0).to(DEV)
     errs = dict(out=_close(out, w_out, "dense gat_forward out"), sum=_close(esum, w_sum, "dense edge_sum"),
@@ -669,9 +673,11 @@ def test_gat_train_dense_every_geometry(oracle_mod, h, f):
     print({k: f"{v:.1e}" for k, v in errs.items()})
     gat.USE_BLOCK_PLAN = False
     try:
-        out_n, emax_n, esum_n, mask_n = gat.gat_forward(ar, ac, row_ptr, col_ind, 0.2, X, 0.0)
-        gf_n, gr_n, gc_n = gat.gat_backward(0.2, 0.0, row_ptr, col_ind, col_ptr, row_ind, val_idx, emax_n, esum_n, mask_n,
-                                            X, ar, ac, dO)
+        torch.manual_seed(77)                                                # the same dropout randoms
+        out_n, emax_n, esum_n, mask_n = gat.gat_forward(ar, ac, row_ptr, col_ind, 0.2, X, attn_drop)
+        assert torch.equal(mask_n, mask)
+        gf_n, gr_n, gc_n = gat.gat_backward(0.2, attn_drop, row_ptr, col_ind, col_ptr, row_ind, val_idx, emax_n, esum_n,
+                                            mask_n, X, ar, ac, dO)
     finally:
         gat.USE_BLOCK_PLAN = True
     for a, b in ((out, out_n), (gf, gf_n), (gr, gr_n), (gc, gc_n), (esum, esum_n)):

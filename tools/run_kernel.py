@@ -36,7 +36,7 @@ if what == "gat":
 if what.startswith("gat_train"):
     import fused_gatconv as gat
     ar, ac, X = S.gat_features(m, 1, 128, seed=6, device=dev)
-    drop = 0.5 if what.endswith("drop") else 0.0
+    drop = 0.5 if what.endswith("drop") else 0.0  # (both take the matrix-core kernels on this batch)
     for _ in range(iters):
         out, emax, esum, mask = gat.gat_forward(ar, ac, row_ptr, col_ind, 0.2, X, drop)
         gat.gat_backward(0.2, drop, row_ptr, col_ind, col_ptr, row_ind, val_idx, emax, esum, mask, X, ar, ac, dO)
