@@ -207,14 +207,16 @@ int dfgnn_gat_attn_scores(int m, int h, int f, const float *a_l, const float *a_
   return launch_gat_attn_scores(m, h, f, a_l, a_r, X, attn_row, attn_col, as_stream(stream));
 }
 
-// The GAT training pair takes the matrix-core kernels when every range of the plan is dense.
+// The GAT training pair serves the dense ranges of a plan with the matrix-core kernels and everything else (its
+// non-dense fit ranges, its spill chunks) with the general kernels restricted to those ranges.
 static bool gat_train_dense(Plan &p, const int *rows, const int *plan, const int *plan_meta, int m, int nnz, int f,
                             bool v4) {
   if (!rows || !v4 || !dense_enabled()) return false;
   if (f != 32 && f != 64 && f != 128) return false;
   if (!make_plan(p, plan, plan_meta, m, nnz, f)) return false;
-  return p.num_dense > 0 && p.num_dense == p.num_fit && p.num_spill == 0;
+  return p.num_dense > 0;
 }
+static bool plan_has_rest(const Plan &p) { return p.num_fit - p.num_dense + p.num_spill > 0; }
 
 int dfgnn_gat_fwd_train(int m, int nnz, int h, int f, const int *row_ptr, const int *col_ind, const int *rows,
                         const float *attn_row, const float *attn_col, float negative_slope, const float *X,
@@ -226,9 +228,14 @@ int dfgnn_gat_fwd_train(int m, int nnz, int h, int f, const int *row_ptr, const 
   const Csr g{m, nnz, h, f, row_ptr, col_ind, rows, nullptr};
   Plan p;
   const bool v4 = (f % 4 == 0) && aligned16(X) && aligned16(out);
-  if (gat_train_dense(p, rows, plan, plan_meta, m, nnz, f, v4))
-    return launch_gat_dense_fwd(g, p, attn_row, attn_col, negative_slope, X, out, as_stream(stream), edge_max,
-                                edge_sum, edge_mask, attn_drop);
+  if (gat_train_dense(p, rows, plan, plan_meta, m, nnz, f, v4)) {
+    if (int rc = launch_gat_dense_fwd(g, p, attn_row, attn_col, negative_slope, X, out, as_stream(stream), edge_max,
+                                      edge_sum, edge_mask, attn_drop))
+      return rc;
+    if (!plan_has_rest(p)) return 0;
+    return launch_gat_train_fwd(g, attn_row, attn_col, negative_slope, X, edge_mask, attn_drop, edge_max, edge_sum,
+                                out, as_stream(stream), &p);
+  }
   return launch_gat_train_fwd(g, attn_row, attn_col, negative_slope, X, edge_mask, attn_drop, edge_max, edge_sum,
                               out, as_stream(stream));
 }
@@ -247,16 +254,21 @@ int dfgnn_gat_bwd(int m, int nnz, int h, int f, const int *row_ptr, const int *c
   const Csr g{m, nnz, h, f, row_ptr, col_ind, rows, nullptr};
   Plan p;
   const bool v4 = (f % 4 == 0) && aligned16(X) && aligned16(grad_out) && aligned16(grad_feat);
-  if (gat_train_dense(p, rows, plan, plan_meta, m, nnz, f, v4))
-    return launch_gat_dense_bwd(g, p, attn_row, attn_col, negative_slope, X, edge_max, edge_sum, grad_out, grad_feat,
-                                grad_attn_row, grad_attn_col, as_stream(stream), edge_mask, attn_drop);
+  const Plan *rest = nullptr;
+  if (gat_train_dense(p, rows, plan, plan_meta, m, nnz, f, v4)) {
+    if (int rc = launch_gat_dense_bwd(g, p, attn_row, attn_col, negative_slope, X, edge_max, edge_sum, grad_out,
+                                      grad_feat, grad_attn_row, grad_attn_col, as_stream(stream), edge_mask, attn_drop))
+      return rc;
+    if (!plan_has_rest(p)) return 0;
+    rest = &p;
+  }
   if (!col_ptr || (nnz > 0 && (!row_ind || !permute || !grad_edge))) return kErrBadArg;
   if (int rc = launch_gat_bwd_rows(g, attn_row, attn_col, negative_slope, X, edge_max, edge_sum, edge_mask,
-                                   attn_drop, grad_out, grad_edge, grad_attn_row, as_stream(stream)))
+                                   attn_drop, grad_out, grad_edge, grad_attn_row, as_stream(stream), rest))
     return rc;
   return launch_gat_bwd_cols(g, col_ptr, row_ind, permute, attn_row, attn_col, negative_slope, edge_max, edge_sum,
-                             edge_mask, attn_drop, grad_edge, grad_out, grad_feat, grad_attn_col,
-                             as_stream(stream));
+                             edge_mask, attn_drop, grad_edge, grad_out, grad_feat, grad_attn_col, as_stream(stream),
+                             rest);
 }
 
 }  // extern "C"

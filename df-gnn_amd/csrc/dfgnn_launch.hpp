@@ -135,16 +135,19 @@ int launch_gat_sddmm(const Csr &g, const float *attn_row, const float *attn_col,
 
 int launch_gat_attn_scores(int m, int h, int f, const float *a_l, const float *a_r, const float *X, float *attn_row,
                            float *attn_col, hipStream_t s);
-// GAT training pair (gat_train.hip)
+// GAT training pair (gat_train.hip).  rest != NULL: only the ranges of that plan which the matrix-core kernels do not
+// serve (its non-dense fit ranges and its spill chunks); NULL: the whole graph.
 int launch_gat_train_fwd(const Csr &g, const float *attn_row, const float *attn_col, float slope, const float *X,
                          const float *edge_mask, float attn_drop, float *edge_max, float *edge_sum, float *out,
-                         hipStream_t s);
+                         hipStream_t s, const Plan *rest = nullptr);
 int launch_gat_bwd_rows(const Csr &g, const float *attn_row, const float *attn_col, float slope, const float *X,
                         const float *edge_max, const float *edge_sum, const float *edge_mask, float attn_drop,
-                        const float *grad_out, float *grad_edge, float *grad_row, hipStream_t s);
+                        const float *grad_out, float *grad_edge, float *grad_row, hipStream_t s,
+                        const Plan *rest = nullptr);
 int launch_gat_bwd_cols(const Csr &g, const int *col_ptr, const int *row_ind, const int *permute,
                         const float *attn_row, const float *attn_col, float slope, const float *edge_max,
                         const float *edge_sum, const float *edge_mask, float attn_drop, const float *grad_edge,
-                        const float *grad_out, float *grad_feat, float *grad_col, hipStream_t s);
+                        const float *grad_out, float *grad_feat, float *grad_col, hipStream_t s,
+                        const Plan *rest = nullptr);
 
 }  // namespace dfgnn

@@ -46,6 +46,26 @@ __device__ __forceinline__ void tile_dots(const Frag<C> &a, const int *cols, int
   }
 }
 
+// Rows (CSR pass) / columns (CSC pass) a launch covers: all of them, grid-strided -- or, next to the matrix-core
+// kernels on a batch with a block plan, only the closed ranges those kernels do not serve: two lists of (n0, n1) pairs
+// (the plan's non-dense fit ranges, whose n1 carries flag bits, and its spill chunks), one workgroup per pair.
+struct RowLists {
+  const int *a, *b;
+  int na, nb;
+};
+__device__ __forceinline__ void row_span(const RowLists &rl, int m, int wave, int &beg, int &end, int &step) {
+  if (rl.na + rl.nb == 0) {
+    beg = blockIdx.x * kWavesPerBlock + wave;
+    end = m;
+    step = gridDim.x * kWavesPerBlock;
+  } else {
+    const int *e = (int)blockIdx.x < rl.na ? rl.a + 2 * blockIdx.x : rl.b + 2 * (blockIdx.x - rl.na);
+    beg = e[0] + wave;
+    end = e[1] & kPlanRangeMask;
+    step = kWavesPerBlock;
+  }
+}
+
 struct GatDrop {         // attention dropout: keep edge e of head hd iff mask[e*h + hd] > drop
   const float *mask;     // uniform randoms [nnz, h]; NULL = keep everything
   float drop, scale;     // scale = 1 / (1 - drop)  (1 when mask == NULL)
@@ -57,7 +77,7 @@ __global__ __launch_bounds__(kBlock) void gat_train_fwd_kernel(Csr g, const floa
                                                                const float *__restrict__ X, GatDrop dr,
                                                                float *__restrict__ edge_max,
                                                                float *__restrict__ edge_sum,
-                                                               float *__restrict__ out) {
+                                                               float *__restrict__ out, RowLists rl) {
   __shared__ __attribute__((aligned(16))) float lds[kWavesPerBlock * kScratchFloatsPerWave];
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
   float *sw = lds + wave * kScratchFloatsPerWave;
@@ -67,7 +87,9 @@ __global__ __launch_bounds__(kBlock) void gat_train_fwd_kernel(Csr g, const floa
   const float *Xh = X + (size_t)head * f;
   const float *acol_h = attn_col + head;
   const int gid = lane / C::G, gl = lane % C::G;
-  for (int r = blockIdx.x * kWavesPerBlock + wave; r < g.m; r += gridDim.x * kWavesPerBlock) {
+  int rbeg, rend, rstep;
+  row_span(rl, g.m, wave, rbeg, rend, rstep);
+  for (int r = rbeg; r < rend; r += rstep) {
     const int lb = g.row_ptr[r], deg = g.row_ptr[r + 1] - lb;
     const float ar = attn_row[(size_t)r * h + head];
     Frag<C> acc;
@@ -108,7 +130,7 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_rows_kernel(Csr g, const float
                                                               const float *__restrict__ edge_sum, GatDrop dr,
                                                               const float *__restrict__ dO,
                                                               float *__restrict__ grad_edge,
-                                                              float *__restrict__ grad_row) {
+                                                              float *__restrict__ grad_row, RowLists rl) {
   __shared__ __attribute__((aligned(16))) float lds[kWavesPerBlock * kScratchFloatsPerWave];
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
   float *sw = lds + wave * kScratchFloatsPerWave;
@@ -119,7 +141,9 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_rows_kernel(Csr g, const float
   const float *acol_h = attn_col + head;
   float *G_h = grad_edge + (size_t)head * g.nnz;
   const int gid = lane / C::G, gl = lane % C::G;
-  for (int r = blockIdx.x * kWavesPerBlock + wave; r < g.m; r += gridDim.x * kWavesPerBlock) {
+  int rbeg, rend, rstep;
+  row_span(rl, g.m, wave, rbeg, rend, rstep);
+  for (int r = rbeg; r < rend; r += rstep) {
     const int lb = g.row_ptr[r], deg = g.row_ptr[r + 1] - lb;
     float rs = 0.f;
     if (deg > 0) {
@@ -186,7 +210,7 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_cols_kernel(Csr g, const int *
                                                               const float *__restrict__ grad_edge,
                                                               const float *__restrict__ dO,
                                                               float *__restrict__ grad_feat,
-                                                              float *__restrict__ grad_col) {
+                                                              float *__restrict__ grad_col, RowLists rl) {
   __shared__ __attribute__((aligned(16))) float lds[kWavesPerBlock * kScratchFloatsPerWave];
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
   float *sw = lds + wave * kScratchFloatsPerWave;
@@ -197,7 +221,9 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_cols_kernel(Csr g, const int *
   const float *arow_h = attn_row + head, *mx_h = edge_max + head, *sum_h = edge_sum + head;
   const float *G_h = grad_edge + (size_t)head * g.nnz;
   const int gid = lane / C::G, gl = lane % C::G;
-  for (int j = blockIdx.x * kWavesPerBlock + wave; j < g.m; j += gridDim.x * kWavesPerBlock) {
+  int jbeg, jend, jstep;
+  row_span(rl, g.m, wave, jbeg, jend, jstep);  // (closed ranges: a range's columns are its rows)
+  for (int j = jbeg; j < jend; j += jstep) {
     const int lb = col_ptr[j], n = col_ptr[j + 1] - lb;
     const float ac = attn_col[(size_t)j * h + head];
     Frag<C> acc;
@@ -229,34 +255,42 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_cols_kernel(Csr g, const int *
   }
 }
 
-static inline int row_grid(int m) {
+static inline int row_grid(int m, const RowLists &rl) {
+  if (rl.na + rl.nb > 0) return rl.na + rl.nb;
   const long want = ((long)m + kWavesPerBlock - 1) / kWavesPerBlock;
   return (int)(want > (1 << 20) ? (1 << 20) : want);
+}
+// the ranges of a plan the matrix-core kernels do not serve (none: the whole graph)
+static inline RowLists rest_of(const Plan *p) {
+  if (!p) return RowLists{nullptr, nullptr, 0, 0};
+  return RowLists{p->fit() + 2 * (size_t)p->num_dense, p->spill(), p->num_fit - p->num_dense, p->num_spill};
 }
 
 int launch_gat_train_fwd(const Csr &g, const float *attn_row, const float *attn_col, float slope, const float *X,
                          const float *edge_mask, float attn_drop, float *edge_max, float *edge_sum, float *out,
-                         hipStream_t s) {
-  const dim3 grid(row_grid(g.m), g.h);
+                         hipStream_t s, const Plan *rest) {
+  const RowLists rl = rest_of(rest);
+  const dim3 grid(row_grid(g.m, rl), g.h);
   const GatDrop dr{edge_mask, attn_drop, edge_mask ? 1.f / (1.f - attn_drop) : 1.f};
   const bool v4 = (g.f % 4 == 0) && aligned16(X) && aligned16(out);
   return dispatch_cfg(g.f, v4, [&](auto cfg) {
     using C = decltype(cfg);
-    gat_train_fwd_kernel<C><<<grid, kBlock, 0, s>>>(g, attn_row, attn_col, slope, X, dr, edge_max, edge_sum, out);
+    gat_train_fwd_kernel<C><<<grid, kBlock, 0, s>>>(g, attn_row, attn_col, slope, X, dr, edge_max, edge_sum, out, rl);
     return launch_status();
   });
 }
 
 int launch_gat_bwd_rows(const Csr &g, const float *attn_row, const float *attn_col, float slope, const float *X,
                         const float *edge_max, const float *edge_sum, const float *edge_mask, float attn_drop,
-                        const float *grad_out, float *grad_edge, float *grad_row, hipStream_t s) {
-  const dim3 grid(row_grid(g.m), g.h);
+                        const float *grad_out, float *grad_edge, float *grad_row, hipStream_t s, const Plan *rest) {
+  const RowLists rl = rest_of(rest);
+  const dim3 grid(row_grid(g.m, rl), g.h);
   const GatDrop dr{edge_mask, attn_drop, edge_mask ? 1.f / (1.f - attn_drop) : 1.f};
   const bool v4 = (g.f % 4 == 0) && aligned16(X) && aligned16(grad_out);
   return dispatch_cfg(g.f, v4, [&](auto cfg) {
     using C = decltype(cfg);
     gat_bwd_rows_kernel<C><<<grid, kBlock, 0, s>>>(g, attn_row, attn_col, slope, X, edge_max, edge_sum, dr,
-                                                   grad_out, grad_edge, grad_row);
+                                                   grad_out, grad_edge, grad_row, rl);
     return launch_status();
   });
 }
@@ -264,14 +298,16 @@ int launch_gat_bwd_rows(const Csr &g, const float *attn_row, const float *attn_c
 int launch_gat_bwd_cols(const Csr &g, const int *col_ptr, const int *row_ind, const int *permute,
                         const float *attn_row, const float *attn_col, float slope, const float *edge_max,
                         const float *edge_sum, const float *edge_mask, float attn_drop, const float *grad_edge,
-                        const float *grad_out, float *grad_feat, float *grad_col, hipStream_t s) {
-  const dim3 grid(row_grid(g.m), g.h);
+                        const float *grad_out, float *grad_feat, float *grad_col, hipStream_t s, const Plan *rest) {
+  const RowLists rl = rest_of(rest);
+  const dim3 grid(row_grid(g.m, rl), g.h);
   const GatDrop dr{edge_mask, attn_drop, edge_mask ? 1.f / (1.f - attn_drop) : 1.f};
   const bool v4 = (g.f % 4 == 0) && aligned16(grad_out) && aligned16(grad_feat);
   return dispatch_cfg(g.f, v4, [&](auto cfg) {
     using C = decltype(cfg);
     gat_bwd_cols_kernel<C><<<grid, kBlock, 0, s>>>(g, col_ptr, row_ind, permute, attn_row, attn_col, slope,
-                                                   edge_max, edge_sum, dr, grad_edge, grad_out, grad_feat, grad_col);
+                                                   edge_max, edge_sum, dr, grad_edge, grad_out, grad_feat, grad_col,
+                                                   rl);
     return launch_status();
   });
 }

@@ -182,9 +182,9 @@ int dfgnn_gat_attn_scores(int m, int h, int f, const float *a_l, const float *a_
  *   fused_gatconv_kernel.cu:1074-1083; the binding draws it with torch.rand so runs are reproducible).
  *   Edge e of head hd is kept iff edge_mask[e*h + hd] > attn_drop and its attention is scaled by
  *   1 / (1 - attn_drop).  NULL = no dropout (attn_drop is then ignored); with a mask, 0 <= attn_drop < 1.
- * rows / plan / plan_meta: optional (NULL = general CSR kernels).  With all three and a plan whose
- *   ranges are all marked dense (meta[9] == meta[0], meta[1] == 0: a batch of small dense graphs), both calls
- *   run on the matrix-core kernels (one workgroup per member graph, as dfgnn_gt_hyper_fwd / dfgnn_gt_bwd do).
+ * rows / plan / plan_meta: optional (NULL = general CSR kernels).  With all three, the plan's dense ranges
+ *   (meta[9] of them: small dense member graphs of a batch) run on the matrix-core kernels, one workgroup per
+ *   range as in dfgnn_gt_hyper_fwd / dfgnn_gt_bwd, and the general kernels cover only the remaining ranges.
  *   The reference's gat_forward / gat_backward take no COO rows: the binding derives them from row_ptr once per
  *   batch structure, next to the plan.
  *

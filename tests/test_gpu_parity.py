@@ -683,16 +683,30 @@ def test_gat_train_dense_every_geometry(oracle_mod, h, f, attn_drop):
     for a, b in ((out, out_n), (gf, gf_n), (gr, gr_n), (gc, gc_n), (esum, esum_n)):
         assert torch.allclose(a, b, atol=2e-4, rtol=1e-3)
     assert not torch.equal(out, out_n)                                       # two different code paths did run
-    # a batch with one non-dense range keeps the general kernels for the whole call (all-or-nothing dispatch)
+    # mixed batch: dense ranges on the matrix cores, the rest -- a graph with a duplicate edge (fit, not dense), a graph
+    # too large for LDS residency (spill chunks), isolated nodes -- on the general kernels restricted to those ranges
     s_, d_ = er(40, 0.6)
-    g2 = batch(graphs[:3] + [Graph(np.concatenate([s_, s_[:1]]), np.concatenate([d_, d_[:1]]), 40)]).to(DEV)
+    big_n = 1500
+    bs_, bd_ = rng.integers(0, big_n, 40000), rng.integers(0, big_n, 40000)
+    g2 = batch(graphs[:3] + [Graph(np.concatenate([s_, s_[:1]]), np.concatenate([d_, d_[:1]]), 40),
+                             Graph(bs_, bd_, big_n)] + graphs[3:6]).to(DEV)
     A, rows, row_ptr, col_ind, val, col_ptr, row_ind, val_idx, smem = preprocess_Hyper_fw_bw(g2)
     m2 = g2.num_nodes()
     ar, ac, X = S.gat_features(m2, h, f, seed=9, device=DEV)
-    out2, emax2, esum2, _ = gat.gat_forward(ar, ac, row_ptr, col_ind, 0.2, X, 0.0)
-    assert row_ptr._dfgnn_plans[f].num_dense < row_ptr._dfgnn_plans[f].num_fit
-    w2, _, _ = oracle_mod.gat_train_forward(n_(row_ptr), n_(col_ind), n_(ar), n_(ac), 0.2, n_(X))
-    _close(out2, w2, "mixed batch gat_forward")
+    dO = torch.randn(m2, h, f, generator=torch.Generator().manual_seed(4)).to(DEV)
+    torch.manual_seed(5)
+    out2, emax2, esum2, mask2 = gat.gat_forward(ar, ac, row_ptr, col_ind, 0.2, X, attn_drop)
+    p2 = row_ptr._dfgnn_plans[f]
+    assert 0 < p2.num_dense < p2.num_fit and p2.num_spill > 0
+    gf2, gr2, gc2 = gat.gat_backward(0.2, attn_drop, row_ptr, col_ind, col_ptr, row_ind, val_idx, emax2, esum2, mask2, X,
+                                     ar, ac, dO)
+    args2 = (n_(row_ptr), n_(col_ind), n_(ar), n_(ac), 0.2, n_(X))
+    mk2 = n_(mask2) if attn_drop > 0 else None
+    w2, _, ws2 = oracle_mod.gat_train_forward(*args2, mk2, attn_drop)
+    wf2, wr2, wc2 = oracle_mod.gat_backward(*args2, n_(dO), mk2, attn_drop)
+    for got, want, what in ((out2, w2, "out"), (esum2, ws2, "edge_sum"), (gf2, wf2, "grad_feat"),
+                            (gr2, wr2, "grad_attn_row"), (gc2, wc2, "grad_attn_col")):
+        _close(got, want, "mixed batch " + what)
 
 
 # ---- GPU-side preprocessing: COO -> CSR / rows / CSC through dfgnn_preprocess_hyper ----------
