@@ -52,6 +52,11 @@ def lib():
             raise RuntimeError(
                 f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950). There is no CPU fallback for the fused kernels.")
+        # torch first: it brings its own HIP runtime (libamdhip64 under torch/lib), and the one that is loaded first is
+        # the one the process uses.  Loaded the other way round, libdfgnn.so pulls in /opt/rocm's runtime and torch
+        # then fails to see the GPU ("No HIP GPUs are available") -- the library itself has no torch dependency, this
+        # only fixes the load order inside a torch process.
+        import torch  # noqa: F401
         L = ctypes.CDLL(LIB_PATH)
         for name, argtypes in SIGNATURES.items():
             fn = getattr(L, name)  # AttributeError if the library is stale
