@@ -876,3 +876,106 @@ def test_multilayer_training_fused_vs_baseline():
     # (Adam normalises the gradient, so compare the weights loosely and their movement from a common init tightly)
     assert torch.allclose(fused["qkv_weights"], base["qkv_weights"], atol=2e-3)
     assert fused["preprocess_ms"] > 0 and fused["layer_edges_per_s"] > 0
+
+
+def _reference_plan(row_ptr, col_ind, f, budget, merge_nodes):
+    """numpy restatement of dfgnn_plan_build's semantics (plan.hip): natural closed ranges, greedy left-to-right merge
+    under the LDS budget / merge cap, classes (spill / edge-global / dense).  Returns (fit list in node order with
+    flags, spill chunks)."""
+    m = len(row_ptr) - 1
+    ends = _natural_ranges(row_ptr, col_ind)
+    dup = np.zeros(m + 1, np.int64)                     # rows with a duplicate edge (or too wide / long) before row i
+    for i in range(m):
+        c = col_ind[row_ptr[i]:row_ptr[i + 1]]
+        lo, hi = (min(i, c.min()), max(i, c.max())) if len(c) else (i, i)
+        bad = 1 if (hi - lo >= 256 or len(c) >= 256) else int(len(np.unique(c)) != len(c))
+        dup[i + 1] = dup[i] + bad
+    lite = lambda n, e: min(n, 1 << 16) * (4 * f + 8) + min(e, 1 << 24) * (1 if min(n, 1 << 16) <= 256 else 2)  # noqa: E731
+    full = lambda n, e: lite(n, e) + 4 * min(e, 1 << 24)  # noqa: E731
+    dense_f = f in (32, 64, 128)
+    fit, spill = [], []
+
+    def flush(n0, n1):
+        if n1 <= n0:
+            return
+        e, nn = int(row_ptr[n1] - row_ptr[n0]), n1 - n0
+        flags = ((1 << 30) if full(nn, e) > budget else 0)
+        if dense_f and nn <= 255 and min(e, 1 << 24) * 32 >= nn * nn and dup[n1] == dup[n0]:
+            flags |= 1 << 29
+        fit.append((n0, n1 | flags))
+
+    cur0 = cur1 = prev = 0
+    for end in ends:
+        n_one, e_one = end - prev, int(row_ptr[end] - row_ptr[prev])
+        if lite(n_one, e_one) > budget:
+            flush(cur0, cur1)
+            spill += [(r, min(end, r + 16)) for r in range(prev, end, 16)]
+            cur0 = cur1 = end
+        elif full(n_one, e_one) > budget:
+            flush(cur0, cur1)
+            flush(prev, end)
+            cur0 = cur1 = end
+        elif cur1 > cur0 and (full(end - cur0, int(row_ptr[end] - row_ptr[cur0])) > budget or end - cur0 > merge_nodes):
+            flush(cur0, cur1)
+            cur0, cur1 = prev, end
+        else:
+            if cur1 == cur0:
+                cur0 = prev
+            cur1 = end
+        prev = end
+    flush(cur0, cur1)
+    return fit, spill
+
+
+@pytest.mark.parametrize("case", ["tiny_graphs_merge", "many_ranges_serial_fallback", "mixed_classes", "duplicates"])
+def test_block_plan_matches_reference_walk(case):
+    """The parallel merge of plan_cut_kernel (and its serial fallback beyond 4096 natural ranges) against a numpy
+    restatement of the greedy walk: same fit ranges with the same flags, same spill chunks."""
+    from _binding_util import build_plan
+    from DFGNN.layers.util import preprocess_Hyper
+    from DFGNN.utils import Graph, batch
+    rng = np.random.default_rng(len(case))
+
+    def clique(n):
+        i, j = np.nonzero(~np.eye(n, dtype=bool))
+        return Graph(i, j, n)
+
+    def er(n, p):
+        iu, ju = np.triu_indices(n, k=1)
+        keep = rng.random(len(iu)) < p
+        return Graph(np.concatenate([iu[keep], ju[keep]]), np.concatenate([ju[keep], iu[keep]]), n)
+
+    f = 128
+    if case == "tiny_graphs_merge":                      # 600 graphs of 9-20 nodes: ~8 merge into each <= 128-node range
+        graphs = [clique(int(n)) for n in rng.integers(9, 21, 600)]
+    elif case == "many_ranges_serial_fallback":           # 5000 natural ranges > 4096
+        graphs = [clique(int(n)) for n in rng.integers(9, 12, 5000)]
+    elif case == "mixed_classes":                         # a range that does not fit (spill), one whose edge array does
+        graphs = [er(40, 0.5), er(700, 0.3), er(60, 0.6), er(250, 0.95), clique(12), clique(30), er(180, 0.5)]
+        f = 64                                            # not (edge-global), merged small ones, dense ones
+    else:
+        g1, g2 = er(50, 0.5), er(70, 0.5)
+        s_, d_ = g1.edges()
+        graphs = [Graph(torch.cat([s_, s_[:3]]), torch.cat([d_, d_[:3]]), 50), g2, clique(10), clique(11)]
+    g = batch(graphs).to(DEV)
+    row_ptr, col_ind, rows, val, smem = preprocess_Hyper(g)
+    plan = build_plan(row_ptr, col_ind, f)
+    rp, ci = row_ptr.cpu().numpy(), col_ind.cpu().numpy()
+    budget = plan.meta[7]
+    want_fit, want_spill = _reference_plan(rp, ci, f, budget, 128)
+    m = g.num_nodes()
+    buf = plan.buf.cpu().numpy()
+    nfit, nspill = plan.meta[0], plan.meta[1]
+    got_fit = sorted(map(tuple, buf[12:12 + 2 * nfit].reshape(-1, 2).tolist()))
+    got_spill = sorted(map(tuple, buf[12 + 2 * m:12 + 2 * m + 2 * nspill].reshape(-1, 2).tolist()))
+    assert got_fit == sorted(want_fit), (case, len(got_fit), len(want_fit))
+    assert got_spill == sorted(want_spill), case
+    FLAGS = (1 << 30) | (1 << 29)
+    n_dense = sum(1 for _, b in want_fit if b & (1 << 29))
+    assert plan.meta[8] == sum(1 for _, b in want_fit if b & (1 << 30))
+    assert plan.num_dense == (n_dense if nfit <= 4096 else 0)
+    assert plan.meta[2] == max((b & ~FLAGS) - a for a, b in want_fit)
+    if case == "mixed_classes":
+        assert nspill > 0 and plan.meta[8] > 0 and n_dense > 0
+    if case == "many_ranges_serial_fallback":
+        assert len(_natural_ranges(rp, ci)) > 4096
