@@ -1,0 +1,8 @@
+"""Full-graph inference harness -- same command line as the reference's DFGNN/script/test/test_full_graph.py."""
+import argparse
+
+from DFGNN.script.harness import run_full_graph
+from DFGNN.utils import parser_argument
+
+if __name__ == "__main__":
+    run_full_graph(parser_argument(argparse.ArgumentParser(description="full-graph inference")))

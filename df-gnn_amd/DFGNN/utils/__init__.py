@@ -1,3 +1,4 @@
+from .datasets import GraphDataLoader, load_data_full_graph, load_dataset_fn, mkdir  # noqa: F401
 from .graph import Graph, batch  # noqa: F401
 from .hipgraph import GraphedStep  # noqa: F401
 from .util import *  # noqa: F401,F403

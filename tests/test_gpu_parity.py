@@ -979,3 +979,24 @@ def test_block_plan_matches_reference_walk(case):
         assert nspill > 0 and plan.meta[8] > 0 and n_dense > 0
     if case == "many_ranges_serial_fallback":
         assert len(_natural_ranges(rp, ci)) > 4096
+
+
+def test_harness_scripts_run_like_the_reference(capsys):
+    """DFGNN/script/test/test_batch_graph.py / test_full_graph.py with the reference's arguments, on the synthetic
+    dataset stand-ins at toy size: every served format of a --format all sweep runs, prints the reference's verdict
+    and result lines, and the fused path is the faster one on the batched GT case."""
+    import argparse
+    import os
+    from DFGNN.script.harness import run_batch_graph, run_full_graph
+    os.environ["DFGNN_SYNTH_GRAPHS"] = "24"
+    ns = dict(config=None, heads=1, data_dir="./data", store_result=False, subgraph_filter=False, profile=False)
+    res = run_batch_graph(argparse.Namespace(conv="gt", format="all", dim=64, batch_size=8, dataset="PATTERN", **ns))
+    assert set(res) == {"csr", "softmax", "hyper"} and all(a > 0 and b > 0 for a, b in res.values())
+    res = run_batch_graph(argparse.Namespace(conv="gat", format="hyper_v2", dim=64, batch_size=8, dataset="PATTERN", **ns))
+    assert "hyper_v2" in res
+    res = run_full_graph(argparse.Namespace(conv="gat", format="all", dim=64, batch_size=None, dataset="cora", **ns))
+    assert set(res) == {"csr", "softmax", "hyper_v2", "tiling", "hyper_recompute"}
+    res = run_full_graph(argparse.Namespace(conv="agnn", format="hyper", dim=64, batch_size=None, dataset="cora", **ns))
+    out = capsys.readouterr().out
+    assert "the results are the same, success!!!!!!!!!!" in out and "fuse average time" in out
+    assert "mismatch" not in out
