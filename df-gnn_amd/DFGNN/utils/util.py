@@ -54,22 +54,27 @@ def benchmark(function, *args):
 
 
 def check_correct(logits, logits_fuse, params=None):
-    """Prints the reference's verdict line; additionally returns True/False so tests can assert."""
+    """The reference's verdict (DFGNN/utils/util.py:211-236): rows are compared with isclose(rtol=1e-3) (atol 1e-8); a
+    row with exactly one element off is tolerated; the first row with more is printed.  Additionally returns
+    True / False so tests can assert."""
     close = torch.isclose(logits, logits_fuse, rtol=0.001)
-    rows_ok = close.reshape(close.shape[0], -1).all(dim=1) if close.dim() > 1 else close
-    if bool(rows_ok.all()):
+    close = close.reshape(close.shape[0], -1) if close.dim() > 1 else close.reshape(-1, 1)
+    misses = (~close).sum(dim=1)
+    failing = torch.argwhere(misses > 1)                 # rows with a single miss pass (:226)
+    if failing.numel() == 0:
         print("the results are the same, success!!!!!!!!!!")
         return True
-    bad = int(torch.argwhere(~rows_ok)[0])
-    # the reference tolerates a single mismatching element per row (:226)
-    row_close = close[bad].reshape(-1)
-    if int(row_close.sum()) + 1 != row_close.numel():
-        print(f"error node {bad} mismatch")
-        print("nonfuse result", logits[bad])
-        print("fuse result", logits_fuse[bad])
-        return False
-    print("the results are the same, success!!!!!!!!!!")
-    return True
+    bad = int(failing[0])
+    print(f"error node {bad} mismatch")
+    print("nonfuse result", logits[bad])
+    print("fuse result", logits_fuse[bad])
+    # The check above is relative only (rtol 1e-3, atol 1e-8): elements within ~1e-3 of zero trip it at an absolute
+    # error of 1e-6.  Say how large the difference actually is (this build's parity bar: 1e-3 + 1e-3 |x|).
+    err = (logits.double() - logits_fuse.double()).abs()
+    if bool((err <= 1e-3 + 1e-3 * logits.double().abs()).all()):
+        print(f"  (max abs difference {float(err.max()):.2e}: inside the 1e-3 parity bar; the relative-only check is "
+              "tripped by near-zero elements.  DFGNN_DENSE=0 selects the fp32 VALU kernels, ~1e-7)")
+    return False
 
 
 def preprocess_dglsp(g, **args):
