@@ -132,6 +132,8 @@ if "c3gat" in args:
 
 if "c5" in args:
     import fused_gtconv as _gtb
+    from DFGNN.utils import GraphedStep
+    runs = []
     for heads, use_plan in ((4, True), (4, False), (8, True), (8, False)):
         _gtb.USE_BLOCK_PLAN = use_plan
         f = 128 // heads
@@ -140,26 +142,31 @@ if "c5" in args:
         m, nnz = g.num_nodes(), g.num_edges()
         Q, K, V = (t.requires_grad_(True) for t in S.gt_features(m, heads, f, seed=3, device=dev))
         dO = torch.randn(m, heads, f, device=dev)
+        gargs = (rows, row_ptr, col_ind, val, col_ptr, row_ind, val_idx, smem)
 
-        def step():
-            out = gt.GTConvFuse_hyper(rows, row_ptr, col_ind, val, col_ptr, row_ind, val_idx, smem, Q, K, V)
+        def step(gargs=gargs, Q=Q, K=K, V=V, dO=dO):
+            out = gt.GTConvFuse_hyper(*gargs, Q, K, V)
             return (out,) + torch.autograd.grad(out, (Q, K, V), dO)
 
-        res, sec = benchmark(step)
-        from DFGNN.utils import GraphedStep
-        import fused_gtconv as _gtraw
-
-        def raw_step():                                  # the same launches as explicit operator calls ...
+        def raw_step(gargs=gargs, Q=Q, K=K, V=V, dO=dO):   # the same launches as explicit operator calls ...
+            rows_, row_ptr_, rest = gargs[0], gargs[1], gargs[2:]
             with torch.no_grad():
-                o, attn = _gtraw.gt_hyper_forward(row_ptr, col_ind, rows, val, col_ptr, row_ind, val_idx, smem, Q, K, V)
-                return [o] + _gtraw.gt_backward(row_ptr, col_ind, rows, val, col_ptr, row_ind, val_idx, smem, Q, K, V,
-                                                attn, dO)
-        graphed = GraphedStep(raw_step)                  # ... recorded once, replayed as one hipGraphLaunch
+                o, attn = _gtb.gt_hyper_forward(row_ptr_, rest[0], rows_, *rest[1:], Q, K, V)
+                return [o] + _gtb.gt_backward(row_ptr_, rest[0], rows_, *rest[1:], Q, K, V, attn, dO)
+
+        res, sec = benchmark(step)                           # (every eager run before the first capture: a captured
+        runs.append((heads, use_plan, f, m, nnz, step, raw_step, res, sec, row_ptr))  # graph keeps its memory pool)
+    for heads, use_plan, f, m, nnz, step, raw_step, res, sec, row_ptr in runs:
+        _gtb.USE_BLOCK_PLAN = use_plan
+        graphed = GraphedStep(raw_step)                      # ... recorded once, replayed as one hipGraphLaunch
         res_g, sec_g = benchmark(graphed.replay)
         assert all(torch.equal(a, b) for a, b in zip(res, res_g))
+        gargs = step.__defaults__[0]
+        Q, K, V, dO = step.__defaults__[1:]
         n = lambda t: t.detach().cpu().numpy()  # noqa: E731
-        want = oracle.gt_forward(n(row_ptr), n(col_ind), n(val), n(Q), n(K), n(V))
-        wq, wk, wv = oracle.gt_backward(n(row_ptr), n(col_ind), n(val), n(Q), n(K), n(V), n(dO))
+        rp, ci, vl = n(gargs[1]), n(gargs[2]), n(gargs[3])
+        want = oracle.gt_forward(rp, ci, vl, n(Q), n(K), n(V))
+        wq, wk, wv = oracle.gt_backward(rp, ci, vl, n(Q), n(K), n(V), n(dO))
         err = max(float(np.abs(n(a).astype(np.float64) - b).max()) for a, b in zip(res, (want, wq, wk, wv)))
         D = 128
         byt = (16 * m * D + 12 * nnz + 4 * (m + 1) + 4 * heads * nnz) + (28 * m * D + 12 * heads * nnz + 16 * nnz + 8 * (m + 1))
