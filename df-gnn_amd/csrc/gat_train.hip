@@ -1,4 +1,5 @@
-// gat_train.hip -- GAT training pair for gfx950, general kernels (any graph, no degree limit).
+// gat_train.hip -- GAT training pair for gfx950, general kernels (any graph, no degree limit) and their lane-group
+// forms for low-degree graphs (gat_rowgroup_*: nnz < 8 m, as for the GT path).
 //
 //   gat_train_fwd_kernel   CSR, a wave per row, 64-edge tiles, online softmax; also writes the row statistics the
 //                          backward recomputes P from (edge_max, edge_sum) and applies attention dropout from a
@@ -13,6 +14,8 @@
 //
 // Layouts as in the reference: edge_max / edge_sum / attn_row / attn_col fp32[m, h]; edge_mask fp32[nnz, h]
 // (EDGE-major, CSR order, fused_gatconv_kernel.cu:101).  grad_edge is this library's scratch, fp32[h, nnz].
+#include <cstdlib>
+
 #include "dfgnn_launch.hpp"
 #include "dfgnn_rows.hpp"
 
@@ -255,6 +258,146 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_cols_kernel(Csr g, const int *
   }
 }
 
+// ---- low-degree graphs (molecules, peptides: ~2 edges per row) -----------------------------------------------------
+// A wave per row wastes most of its lanes there; as in gt_lowdeg.hip every group of G lanes (one feature row wide)
+// owns one (row, head): EPW rows per wave, everything in registers, loops to each group's own degree.  The logits
+// are scalars, so the row statistics are exact two-sweep values (no online rescaling).
+template <class C>
+__global__ __launch_bounds__(kBlock) void gat_rowgroup_fwd_kernel(Csr g, const float *__restrict__ attn_row,
+                                                                  const float *__restrict__ attn_col, float slope,
+                                                                  const float *__restrict__ X, GatDrop dr,
+                                                                  float *__restrict__ edge_max,
+                                                                  float *__restrict__ edge_sum,
+                                                                  float *__restrict__ out) {
+  constexpr int G = C::G;
+  const int head = blockIdx.y, h = g.h, f = g.f;
+  const size_t hf = (size_t)h * f, hoff = (size_t)head * f;
+  const int gl = threadIdx.x % G;
+  const int ngroups = gridDim.x * (kBlock / G);
+  for (int r = blockIdx.x * (kBlock / G) + threadIdx.x / G; r < g.m; r += ngroups) {
+    const int lb = g.row_ptr[r], deg = g.row_ptr[r + 1] - lb;
+    const float ar = attn_row[(size_t)r * h + head];
+    float mx = -INFINITY;
+    for (int e = 0; e < deg; ++e)
+      mx = fmaxf(mx, leaky_relu(ar + attn_col[(size_t)g.col_ind[lb + e] * h + head], slope));
+    Frag<C> acc;
+    frag_zero<C>(acc);
+    float sum = 0.f;
+    for (int e = 0; e < deg; ++e) {
+      const int c = g.col_ind[lb + e];
+      const float p = fast_exp(leaky_relu(ar + attn_col[(size_t)c * h + head], slope) - mx);
+      sum += p;  // the row sum counts every edge, dropped or not
+      const bool keep = dr.mask ? dr.mask[(size_t)(lb + e) * h + head] > dr.drop : true;
+      Frag<C> x;
+      frag_load<C>(x, X + (size_t)c * hf + hoff, f, gl);
+      frag_fma<C>(acc, keep ? p : 0.f, x);
+    }
+    frag_store_scaled<C>(acc, sum != 0.f ? dr.scale / sum : 0.f, out + (size_t)r * hf + hoff, f, gl);
+    if (gl == 0) {
+      edge_max[(size_t)r * h + head] = deg > 0 ? mx : -1e38f;
+      edge_sum[(size_t)r * h + head] = sum;
+    }
+  }
+}
+
+template <class C>
+__global__ __launch_bounds__(kBlock) void gat_rowgroup_bwd_rows_kernel(Csr g, const float *__restrict__ attn_row,
+                                                                       const float *__restrict__ attn_col, float slope,
+                                                                       const float *__restrict__ X,
+                                                                       const float *__restrict__ edge_max,
+                                                                       const float *__restrict__ edge_sum, GatDrop dr,
+                                                                       const float *__restrict__ dO,
+                                                                       float *__restrict__ grad_edge,
+                                                                       float *__restrict__ grad_row) {
+  constexpr int G = C::G;
+  const int head = blockIdx.y, h = g.h, f = g.f;
+  const size_t hf = (size_t)h * f, hoff = (size_t)head * f;
+  const int gl = threadIdx.x % G;
+  const int ngroups = gridDim.x * (kBlock / G);
+  float *G_h = grad_edge + (size_t)head * g.nnz;
+  for (int r = blockIdx.x * (kBlock / G) + threadIdx.x / G; r < g.m; r += ngroups) {
+    const int lb = g.row_ptr[r], deg = g.row_ptr[r + 1] - lb;
+    float rs = 0.f;
+    if (deg > 0) {
+      const float ar = attn_row[(size_t)r * h + head];
+      const float mx = edge_max[(size_t)r * h + head], inv = 1.f / edge_sum[(size_t)r * h + head];
+      Frag<C> go;
+      frag_load<C>(go, dO + (size_t)r * hf + hoff, f, gl);
+      float t = 0.f;
+      for (int e = 0; e < deg; ++e) {  // g_e parked in grad_edge (every lane of the group holds the same value)
+        const int c = g.col_ind[lb + e];
+        Frag<C> x;
+        frag_load<C>(x, X + (size_t)c * hf + hoff, f, gl);
+        const float dp = lanes_sum<G>(frag_dot<C>(go, x));
+        const bool keep = dr.mask ? dr.mask[(size_t)(lb + e) * h + head] > dr.drop : true;
+        const float ge = keep ? dp * dr.scale : 0.f;
+        const float p = fast_exp(leaky_relu(ar + attn_col[(size_t)c * h + head], slope) - mx) * inv;
+        t = fmaf(p, ge, t);
+        if (gl == 0) G_h[lb + e] = ge;
+      }
+      for (int e = 0; e < deg; ++e) {
+        const float pre = ar + attn_col[(size_t)g.col_ind[lb + e] * h + head];
+        const float p = fast_exp(leaky_relu(pre, slope) - mx) * inv;
+        // lane 0 re-reads what it parked; the other lanes only need rs, which lane 0 writes
+        const float ge = (gl == 0) ? p * (G_h[lb + e] - t) * (pre > 0.f ? 1.f : slope) : 0.f;
+        if (gl == 0) G_h[lb + e] = ge;
+        rs += ge;
+      }
+    }
+    if (gl == 0) grad_row[(size_t)r * h + head] = rs;
+  }
+}
+
+template <class C>
+__global__ __launch_bounds__(kBlock) void gat_rowgroup_bwd_cols_kernel(
+    Csr g, const int *__restrict__ col_ptr, const int *__restrict__ row_ind, const int *__restrict__ permute,
+    const float *__restrict__ attn_row, const float *__restrict__ attn_col, float slope,
+    const float *__restrict__ edge_max, const float *__restrict__ edge_sum, GatDrop dr,
+    const float *__restrict__ grad_edge, const float *__restrict__ dO, float *__restrict__ grad_feat,
+    float *__restrict__ grad_col) {
+  constexpr int G = C::G;
+  const int head = blockIdx.y, h = g.h, f = g.f;
+  const size_t hf = (size_t)h * f, hoff = (size_t)head * f;
+  const int gl = threadIdx.x % G;
+  const int ngroups = gridDim.x * (kBlock / G);
+  const float *G_h = grad_edge + (size_t)head * g.nnz;
+  for (int j = blockIdx.x * (kBlock / G) + threadIdx.x / G; j < g.m; j += ngroups) {
+    const int lb = col_ptr[j], n = col_ptr[j + 1] - lb;
+    const float ac = attn_col[(size_t)j * h + head];
+    Frag<C> acc;
+    frag_zero<C>(acc);
+    float gs = 0.f;
+    for (int t = 0; t < n; ++t) {
+      const int i = row_ind[lb + t], e = permute[lb + t];
+      const float p = fast_exp(leaky_relu(attn_row[(size_t)i * h + head] + ac, slope) - edge_max[(size_t)i * h + head]) /
+                      edge_sum[(size_t)i * h + head];
+      const bool keep = dr.mask ? dr.mask[(size_t)e * h + head] > dr.drop : true;
+      Frag<C> go;
+      frag_load<C>(go, dO + (size_t)i * hf + hoff, f, gl);
+      frag_fma<C>(acc, keep ? p * dr.scale : 0.f, go);
+      gs += G_h[e];
+    }
+    frag_store_scaled<C>(acc, 1.f, grad_feat + (size_t)j * hf + hoff, f, gl);
+    if (gl == 0) grad_col[(size_t)j * h + head] = gs;
+  }
+}
+
+// DFGNN_LOWDEG=0 in the environment (diagnostic switch, read once) keeps low-degree graphs on the wave-per-row kernels
+static bool lowdeg_enabled() {
+  static const bool on = [] { const char *e = getenv("DFGNN_LOWDEG"); return !e || atoi(e) != 0; }();
+  return on;
+}
+static inline bool use_rowgroup(const Csr &g, const Plan *rest) {
+  return !rest && lowdeg_enabled() && low_degree(g.m, g.nnz);
+}
+
+static dim3 rowgroup_grid(const Csr &g, int G) {
+  const long per = kBlock / G;
+  long blocks = ((long)g.m + per - 1) / per;
+  if (blocks > 16384) blocks = 16384;
+  return dim3((unsigned)(blocks < 1 ? 1 : blocks), g.h);
+}
+
 static inline int row_grid(int m, const RowLists &rl) {
   if (rl.na + rl.nb > 0) return rl.na + rl.nb;
   const long want = ((long)m + kWavesPerBlock - 1) / kWavesPerBlock;
@@ -275,7 +418,11 @@ int launch_gat_train_fwd(const Csr &g, const float *attn_row, const float *attn_
   const bool v4 = (g.f % 4 == 0) && aligned16(X) && aligned16(out);
   return dispatch_cfg(g.f, v4, [&](auto cfg) {
     using C = decltype(cfg);
-    gat_train_fwd_kernel<C><<<grid, kBlock, 0, s>>>(g, attn_row, attn_col, slope, X, dr, edge_max, edge_sum, out, rl);
+    if (use_rowgroup(g, rest))
+      gat_rowgroup_fwd_kernel<C><<<rowgroup_grid(g, C::G), kBlock, 0, s>>>(g, attn_row, attn_col, slope, X, dr, edge_max,
+                                                                          edge_sum, out);
+    else
+      gat_train_fwd_kernel<C><<<grid, kBlock, 0, s>>>(g, attn_row, attn_col, slope, X, dr, edge_max, edge_sum, out, rl);
     return launch_status();
   });
 }
@@ -289,8 +436,12 @@ int launch_gat_bwd_rows(const Csr &g, const float *attn_row, const float *attn_c
   const bool v4 = (g.f % 4 == 0) && aligned16(X) && aligned16(grad_out);
   return dispatch_cfg(g.f, v4, [&](auto cfg) {
     using C = decltype(cfg);
-    gat_bwd_rows_kernel<C><<<grid, kBlock, 0, s>>>(g, attn_row, attn_col, slope, X, edge_max, edge_sum, dr,
-                                                   grad_out, grad_edge, grad_row, rl);
+    if (use_rowgroup(g, rest))
+      gat_rowgroup_bwd_rows_kernel<C><<<rowgroup_grid(g, C::G), kBlock, 0, s>>>(g, attn_row, attn_col, slope, X, edge_max,
+                                                                               edge_sum, dr, grad_out, grad_edge, grad_row);
+    else
+      gat_bwd_rows_kernel<C><<<grid, kBlock, 0, s>>>(g, attn_row, attn_col, slope, X, edge_max, edge_sum, dr, grad_out,
+                                                     grad_edge, grad_row, rl);
     return launch_status();
   });
 }
@@ -305,9 +456,13 @@ int launch_gat_bwd_cols(const Csr &g, const int *col_ptr, const int *row_ind, co
   const bool v4 = (g.f % 4 == 0) && aligned16(grad_out) && aligned16(grad_feat);
   return dispatch_cfg(g.f, v4, [&](auto cfg) {
     using C = decltype(cfg);
-    gat_bwd_cols_kernel<C><<<grid, kBlock, 0, s>>>(g, col_ptr, row_ind, permute, attn_row, attn_col, slope,
-                                                   edge_max, edge_sum, dr, grad_edge, grad_out, grad_feat, grad_col,
-                                                   rl);
+    if (use_rowgroup(g, rest))
+      gat_rowgroup_bwd_cols_kernel<C><<<rowgroup_grid(g, C::G), kBlock, 0, s>>>(
+          g, col_ptr, row_ind, permute, attn_row, attn_col, slope, edge_max, edge_sum, dr, grad_edge, grad_out, grad_feat,
+          grad_col);
+    else
+      gat_bwd_cols_kernel<C><<<grid, kBlock, 0, s>>>(g, col_ptr, row_ind, permute, attn_row, attn_col, slope, edge_max,
+                                                     edge_sum, dr, grad_edge, grad_out, grad_feat, grad_col, rl);
     return launch_status();
   });
 }

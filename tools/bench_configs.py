@@ -97,7 +97,10 @@ if "c4" in args:
 if "gattrain" in args:
     import fused_gatconv as _gatb
     from DFGNN.layers import preprocess_Hyper_fw_bw as _prep
-    for name, graph in (("cora-like", S.cora_like()), (f"reddit-like (scale {scale})", S.reddit_like(scale=scale))):
+    graphs = [("cora-like", S.cora_like()), ("Peptides-like bs=256", S.peptides_like(batch_size=256, seed=3))]
+    if "--no-reddit" not in sys.argv:
+        graphs.append((f"reddit-like (scale {scale})", S.reddit_like(scale=scale)))
+    for name, graph in graphs:
         g = graph.to(dev)
         A, rows, row_ptr, col_ind, val, col_ptr, row_ind, val_idx, smem = _prep(g)
         m, nnz = g.num_nodes(), g.num_edges()
