@@ -1,16 +1,19 @@
-// gat_train.hip -- GAT training pair for gfx950, general kernels (any graph, no degree limit) and their lane-group
-// forms for low-degree graphs (gat_rowgroup_*: nnz < 8 m, as for the GT path).
+// gat_train.hip -- GAT training pair for gfx950: general kernels (any graph, no degree limit).
 //
-//   gat_train_fwd_kernel   CSR, a wave per row, 64-edge tiles, online softmax; also writes the row statistics the
-//                          backward recomputes P from (edge_max, edge_sum) and applies attention dropout from a
-//                          caller-provided tensor of uniform randoms.  replaces fused_forward_kernel
-//                          (DFGNN/src/fused_gatconv/fused_gatconv_kernel.cu:24-125; launcher :1062-1129)
-//   gat_bwd_rows_kernel    CSR pass: dP_e = <dO[i], X[j]>, g_e = keep_e dP_e / (1 - drop),
-//                          G_e = P_e (g_e - sum_row P g) LeakyReLU'(pre_e) -> grad_edge; grad_attn_row[i] = sum_e G_e.
-//                          replaces mhsddmm + fused_backward_kernel (fused_gatconv_kernel.cu:711-865)
-//   gat_bwd_cols_kernel    CSC pass: grad_feat[j] = sum_{e->j} keep_e P_e / (1 - drop) dO[i],
-//                          grad_attn_col[j] = sum_{e->j} G_e.  replaces mhspmm_backward_kernel (:609-660) and the
-//                          atomicAdd into grad_attn_col (:853): the column sums are deterministic here.
+// Three passes, each as a per-row routine in two forms -- a wave per row (64-edge tiles) and, for low-degree graphs
+// (nnz < 8 m, as on the GT path), a group of G lanes per row:
+//   forward           CSR, online softmax; also writes the row statistics the backward recomputes P from
+//                     (edge_max, edge_sum) and applies attention dropout from a caller-provided tensor of uniform
+//                     randoms.  replaces fused_forward_kernel (DFGNN/src/fused_gatconv/fused_gatconv_kernel.cu:24-125;
+//                     launcher :1062-1129)
+//   backward, CSR     dP_e = <dO[i], X[j]>, g_e = keep_e dP_e / (1 - drop), G_e = P_e (g_e - sum_row P g)
+//                     LeakyReLU'(pre_e) -> grad_edge; grad_attn_row[i] = sum_e G_e.  replaces mhsddmm +
+//                     fused_backward_kernel (fused_gatconv_kernel.cu:711-865)
+//   backward, CSC     grad_feat[j] = sum_{e->j} keep_e P_e / (1 - drop) dO[i], grad_attn_col[j] = sum_{e->j} G_e.
+//                     replaces mhspmm_backward_kernel (:609-660) and the atomicAdd into grad_attn_col (:853): the
+//                     column sums are deterministic here.
+// gat_train_wave_kernel runs the wave form over the whole graph or over the ranges a block plan leaves to it;
+// gat_train_group_kernel runs the lane-group form and hands any 16-row block that holds a long row to the wave form.
 //
 // Layouts as in the reference: edge_max / edge_sum / attn_row / attn_col fp32[m, h]; edge_mask fp32[nnz, h]
 // (EDGE-major, CSR order, fused_gatconv_kernel.cu:101).  grad_edge is this library's scratch, fp32[h, nnz].
@@ -74,311 +77,286 @@ struct GatDrop {         // attention dropout: keep edge e of head hd iff mask[e
   float drop, scale;     // scale = 1 / (1 - drop)  (1 when mask == NULL)
 };
 
+// Everything the per-row routines need (pointers already offset to the head where that is a plain offset).
+struct GatTrain {
+  int m, nnz, h, f, head;
+  size_t hf;
+  const int *row_ptr, *col_ind;                 // CSR
+  const int *col_ptr, *row_ind, *permute;       // CSC (column pass)
+  const float *attn_row, *attn_col;             // [m, h]
+  float slope;
+  const float *Xh, *dOh;                        // features / output gradient, + head * f
+  float *edge_max, *edge_sum;                   // [m, h]  (written by the forward, read by the backward)
+  GatDrop dr;
+  float *outh, *gfeath;                         // out / grad_feat, + head * f
+  float *G_h;                                   // grad_edge + head * nnz
+  float *grad_row, *grad_col;                   // [m, h]
+  __device__ __forceinline__ size_t nh(int node) const { return (size_t)node * h + head; }
+  __device__ __forceinline__ bool keep(int e) const { return dr.mask ? dr.mask[(size_t)e * h + head] > dr.drop : true; }
+};
+
+// ======================================================================================================================
+// a wave per row (64-edge tiles; sw / sc: the wave's 64-float / 64-int LDS scratch)
+// ======================================================================================================================
 template <class C>
-__global__ __launch_bounds__(kBlock) void gat_train_fwd_kernel(Csr g, const float *__restrict__ attn_row,
-                                                               const float *__restrict__ attn_col, float slope,
-                                                               const float *__restrict__ X, GatDrop dr,
-                                                               float *__restrict__ edge_max,
-                                                               float *__restrict__ edge_sum,
-                                                               float *__restrict__ out, RowLists rl) {
-  __shared__ __attribute__((aligned(16))) float lds[kWavesPerBlock * kScratchFloatsPerWave];
-  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
-  float *sw = lds + wave * kScratchFloatsPerWave;
-  int *sc = reinterpret_cast<int *>(sw + kWave);
-  const int head = blockIdx.y, h = g.h, f = g.f;
-  const size_t hf = (size_t)h * f;
-  const float *Xh = X + (size_t)head * f;
-  const float *acol_h = attn_col + head;
+__device__ __forceinline__ void gat_fwd_row_wave(const GatTrain &a, int r, int lane, float *sw, int *sc) {
   const int gid = lane / C::G, gl = lane % C::G;
-  int rbeg, rend, rstep;
-  row_span(rl, g.m, wave, rbeg, rend, rstep);
-  for (int r = rbeg; r < rend; r += rstep) {
-    const int lb = g.row_ptr[r], deg = g.row_ptr[r + 1] - lb;
-    const float ar = attn_row[(size_t)r * h + head];
-    Frag<C> acc;
-    frag_zero<C>(acc);
-    float m_run = -INFINITY, l_run = 0.f;
+  const int lb = a.row_ptr[r], deg = a.row_ptr[r + 1] - lb;
+  const float ar = a.attn_row[a.nh(r)];
+  Frag<C> acc;
+  frag_zero<C>(acc);
+  float m_run = -INFINITY, l_run = 0.f;
+  for (int t0 = 0; t0 < deg; t0 += kWave) {
+    const int nt = min(kWave, deg - t0);
+    float s = -INFINITY;
+    int c = 0;
+    bool keep = true;
+    if (lane < nt) {
+      c = a.col_ind[lb + t0 + lane];
+      s = leaky_relu(ar + a.attn_col[a.nh(c)], a.slope);
+      keep = a.keep(lb + t0 + lane);
+    }
+    sc[lane] = c;
+    online_step<C>(s, lane, sw, acc, m_run, l_run);  // the row sum counts every edge, dropped or not
+    if (!keep) sw[lane] = 0.f;
+    wave_sync();
+    spmm_accum<C>(acc, sw, sc, nt, a.Xh, a.hf, a.f, gid, gl);
+    wave_sync();
+  }
+  const float inv = (l_run != 0.f) ? a.dr.scale / l_run : 0.f;
+  frag_reduce_groups<C>(acc);
+  if (gid == 0) frag_store_scaled<C>(acc, inv, a.outh + (size_t)r * a.hf, a.f, gl);
+  if (lane == 0) {
+    a.edge_max[a.nh(r)] = deg > 0 ? m_run : -1e38f;  // the reference's sentinel (fused_gatconv_kernel.cu:46, 66)
+    a.edge_sum[a.nh(r)] = l_run;
+  }
+}
+
+template <class C>
+__device__ __forceinline__ void gat_bwd_row_wave(const GatTrain &a, int r, int lane, float *sw, int *sc) {
+  const int gid = lane / C::G, gl = lane % C::G;
+  const int lb = a.row_ptr[r], deg = a.row_ptr[r + 1] - lb;
+  float rs = 0.f;
+  if (deg > 0) {
+    const float ar = a.attn_row[a.nh(r)];
+    const float mx = a.edge_max[a.nh(r)], inv = 1.f / a.edge_sum[a.nh(r)];
+    Frag<C> go;
+    frag_load<C>(go, a.dOh + (size_t)r * a.hf, a.f, gl);
+    // sweep 1: g_e and t = sum_e P_e g_e.  Single-tile rows keep (P, g, slope factor) in registers; longer rows
+    // park g_e in grad_edge and recompute P in sweep 2.
+    float t = 0.f, p_keep = 0.f, g_keep = 0.f, lr_keep = 0.f;
     for (int t0 = 0; t0 < deg; t0 += kWave) {
       const int nt = min(kWave, deg - t0);
-      float s = -INFINITY;
       int c = 0;
-      bool keep = true;
-      if (lane < nt) {
-        c = g.col_ind[lb + t0 + lane];
-        s = leaky_relu(ar + acol_h[(size_t)c * h], slope);
-        if (dr.mask) keep = dr.mask[(size_t)(lb + t0 + lane) * h + head] > dr.drop;
-      }
+      if (lane < nt) c = a.col_ind[lb + t0 + lane];
       sc[lane] = c;
-      online_step<C>(s, lane, sw, acc, m_run, l_run);  // the row sum counts every edge, dropped or not
-      if (!keep) sw[lane] = 0.f;
       wave_sync();
-      spmm_accum<C>(acc, sw, sc, nt, Xh, hf, f, gid, gl);
+      tile_dots<C>(go, sc, nt, a.Xh, a.hf, a.f, gid, gl, sw);
       wave_sync();
-    }
-    const float inv = (l_run != 0.f) ? dr.scale / l_run : 0.f;
-    frag_reduce_groups<C>(acc);
-    if (gid == 0) frag_store_scaled<C>(acc, inv, out + (size_t)r * hf + (size_t)head * f, f, gl);
-    if (lane == 0) {
-      edge_max[(size_t)r * h + head] = deg > 0 ? m_run : -1e38f;  // the reference's sentinel (:46, :66)
-      edge_sum[(size_t)r * h + head] = l_run;
-    }
-  }
-}
-
-template <class C>
-__global__ __launch_bounds__(kBlock) void gat_bwd_rows_kernel(Csr g, const float *__restrict__ attn_row,
-                                                              const float *__restrict__ attn_col, float slope,
-                                                              const float *__restrict__ X,
-                                                              const float *__restrict__ edge_max,
-                                                              const float *__restrict__ edge_sum, GatDrop dr,
-                                                              const float *__restrict__ dO,
-                                                              float *__restrict__ grad_edge,
-                                                              float *__restrict__ grad_row, RowLists rl) {
-  __shared__ __attribute__((aligned(16))) float lds[kWavesPerBlock * kScratchFloatsPerWave];
-  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
-  float *sw = lds + wave * kScratchFloatsPerWave;
-  int *sc = reinterpret_cast<int *>(sw + kWave);
-  const int head = blockIdx.y, h = g.h, f = g.f;
-  const size_t hf = (size_t)h * f;
-  const float *Xh = X + (size_t)head * f, *dOh = dO + (size_t)head * f;
-  const float *acol_h = attn_col + head;
-  float *G_h = grad_edge + (size_t)head * g.nnz;
-  const int gid = lane / C::G, gl = lane % C::G;
-  int rbeg, rend, rstep;
-  row_span(rl, g.m, wave, rbeg, rend, rstep);
-  for (int r = rbeg; r < rend; r += rstep) {
-    const int lb = g.row_ptr[r], deg = g.row_ptr[r + 1] - lb;
-    float rs = 0.f;
-    if (deg > 0) {
-      const float ar = attn_row[(size_t)r * h + head];
-      const float mx = edge_max[(size_t)r * h + head], inv = 1.f / edge_sum[(size_t)r * h + head];
-      Frag<C> go;
-      frag_load<C>(go, dOh + (size_t)r * hf, f, gl);
-      // sweep 1: g_e and t = sum_e P_e g_e.  Single-tile rows keep (P, g, slope factor) in registers; longer rows
-      // park g_e in grad_edge and recompute P in sweep 2.
-      float t = 0.f, p_keep = 0.f, g_keep = 0.f, lr_keep = 0.f;
-      for (int t0 = 0; t0 < deg; t0 += kWave) {
-        const int nt = min(kWave, deg - t0);
-        int c = 0;
-        if (lane < nt) c = g.col_ind[lb + t0 + lane];
-        sc[lane] = c;
-        wave_sync();
-        tile_dots<C>(go, sc, nt, Xh, hf, f, gid, gl, sw);
-        wave_sync();
-        if (lane < nt) {
-          const int e = lb + t0 + lane;
-          const float pre = ar + acol_h[(size_t)c * h];
-          const float p = fast_exp(leaky_relu(pre, slope) - mx) * inv;
-          const bool keep = dr.mask ? dr.mask[(size_t)e * h + head] > dr.drop : true;
-          const float ge = keep ? sw[lane] * dr.scale : 0.f;
-          t = fmaf(p, ge, t);
-          p_keep = p;
-          g_keep = ge;
-          lr_keep = pre > 0.f ? 1.f : slope;
-          if (deg > kWave) G_h[e] = ge;
-        }
-        wave_sync();
-      }
-      t = lanes_sum<kWave>(t);
-      if (deg <= kWave) {
-        float ge = 0.f;
-        if (lane < deg) {
-          ge = p_keep * (g_keep - t) * lr_keep;
-          G_h[lb + lane] = ge;
-        }
-        rs = lanes_sum<kWave>(ge);
-      } else {
-        for (int e = lb + lane; e < lb + deg; e += kWave) {
-          const float pre = ar + acol_h[(size_t)g.col_ind[e] * h];
-          const float p = fast_exp(leaky_relu(pre, slope) - mx) * inv;
-          const float ge = p * (G_h[e] - t) * (pre > 0.f ? 1.f : slope);  // this lane parked G_h[e] in sweep 1
-          G_h[e] = ge;
-          rs += ge;
-        }
-        rs = lanes_sum<kWave>(rs);
-      }
-    }
-    if (lane == 0) grad_row[(size_t)r * h + head] = rs;
-  }
-}
-
-template <class C>
-__global__ __launch_bounds__(kBlock) void gat_bwd_cols_kernel(Csr g, const int *__restrict__ col_ptr,
-                                                              const int *__restrict__ row_ind,
-                                                              const int *__restrict__ permute,
-                                                              const float *__restrict__ attn_row,
-                                                              const float *__restrict__ attn_col, float slope,
-                                                              const float *__restrict__ edge_max,
-                                                              const float *__restrict__ edge_sum, GatDrop dr,
-                                                              const float *__restrict__ grad_edge,
-                                                              const float *__restrict__ dO,
-                                                              float *__restrict__ grad_feat,
-                                                              float *__restrict__ grad_col, RowLists rl) {
-  __shared__ __attribute__((aligned(16))) float lds[kWavesPerBlock * kScratchFloatsPerWave];
-  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
-  float *sw = lds + wave * kScratchFloatsPerWave;
-  int *sc = reinterpret_cast<int *>(sw + kWave);
-  const int head = blockIdx.y, h = g.h, f = g.f;
-  const size_t hf = (size_t)h * f;
-  const float *dOh = dO + (size_t)head * f;
-  const float *arow_h = attn_row + head, *mx_h = edge_max + head, *sum_h = edge_sum + head;
-  const float *G_h = grad_edge + (size_t)head * g.nnz;
-  const int gid = lane / C::G, gl = lane % C::G;
-  int jbeg, jend, jstep;
-  row_span(rl, g.m, wave, jbeg, jend, jstep);  // (closed ranges: a range's columns are its rows)
-  for (int j = jbeg; j < jend; j += jstep) {
-    const int lb = col_ptr[j], n = col_ptr[j + 1] - lb;
-    const float ac = attn_col[(size_t)j * h + head];
-    Frag<C> acc;
-    frag_zero<C>(acc);
-    float gs = 0.f;
-    for (int t0 = 0; t0 < n; t0 += kWave) {
-      const int nt = min(kWave, n - t0);
-      float w = 0.f;
-      int i = 0;
       if (lane < nt) {
-        i = row_ind[lb + t0 + lane];
-        const int e = permute[lb + t0 + lane];
-        const float pre = arow_h[(size_t)i * h] + ac;
-        const float p = fast_exp(leaky_relu(pre, slope) - mx_h[(size_t)i * h]) / sum_h[(size_t)i * h];
-        const bool keep = dr.mask ? dr.mask[(size_t)e * h + head] > dr.drop : true;
-        w = keep ? p * dr.scale : 0.f;
-        gs += G_h[e];
-      }
-      sw[lane] = w;
-      sc[lane] = i;
-      wave_sync();
-      spmm_accum<C>(acc, sw, sc, nt, dOh, hf, f, gid, gl);
-      wave_sync();
-    }
-    frag_reduce_groups<C>(acc);
-    if (gid == 0) frag_store_scaled<C>(acc, 1.f, grad_feat + (size_t)j * hf + (size_t)head * f, f, gl);
-    gs = lanes_sum<kWave>(gs);
-    if (lane == 0) grad_col[(size_t)j * h + head] = gs;
-  }
-}
-
-// ---- low-degree graphs (molecules, peptides: ~2 edges per row) -----------------------------------------------------
-// A wave per row wastes most of its lanes there; as in gt_lowdeg.hip every group of G lanes (one feature row wide)
-// owns one (row, head): EPW rows per wave, everything in registers, loops to each group's own degree.  The logits
-// are scalars, so the row statistics are exact two-sweep values (no online rescaling).
-template <class C>
-__global__ __launch_bounds__(kBlock) void gat_rowgroup_fwd_kernel(Csr g, const float *__restrict__ attn_row,
-                                                                  const float *__restrict__ attn_col, float slope,
-                                                                  const float *__restrict__ X, GatDrop dr,
-                                                                  float *__restrict__ edge_max,
-                                                                  float *__restrict__ edge_sum,
-                                                                  float *__restrict__ out) {
-  constexpr int G = C::G;
-  const int head = blockIdx.y, h = g.h, f = g.f;
-  const size_t hf = (size_t)h * f, hoff = (size_t)head * f;
-  const int gl = threadIdx.x % G;
-  const int ngroups = gridDim.x * (kBlock / G);
-  for (int r = blockIdx.x * (kBlock / G) + threadIdx.x / G; r < g.m; r += ngroups) {
-    const int lb = g.row_ptr[r], deg = g.row_ptr[r + 1] - lb;
-    const float ar = attn_row[(size_t)r * h + head];
-    float mx = -INFINITY;
-    for (int e = 0; e < deg; ++e)
-      mx = fmaxf(mx, leaky_relu(ar + attn_col[(size_t)g.col_ind[lb + e] * h + head], slope));
-    Frag<C> acc;
-    frag_zero<C>(acc);
-    float sum = 0.f;
-    for (int e = 0; e < deg; ++e) {
-      const int c = g.col_ind[lb + e];
-      const float p = fast_exp(leaky_relu(ar + attn_col[(size_t)c * h + head], slope) - mx);
-      sum += p;  // the row sum counts every edge, dropped or not
-      const bool keep = dr.mask ? dr.mask[(size_t)(lb + e) * h + head] > dr.drop : true;
-      Frag<C> x;
-      frag_load<C>(x, X + (size_t)c * hf + hoff, f, gl);
-      frag_fma<C>(acc, keep ? p : 0.f, x);
-    }
-    frag_store_scaled<C>(acc, sum != 0.f ? dr.scale / sum : 0.f, out + (size_t)r * hf + hoff, f, gl);
-    if (gl == 0) {
-      edge_max[(size_t)r * h + head] = deg > 0 ? mx : -1e38f;
-      edge_sum[(size_t)r * h + head] = sum;
-    }
-  }
-}
-
-template <class C>
-__global__ __launch_bounds__(kBlock) void gat_rowgroup_bwd_rows_kernel(Csr g, const float *__restrict__ attn_row,
-                                                                       const float *__restrict__ attn_col, float slope,
-                                                                       const float *__restrict__ X,
-                                                                       const float *__restrict__ edge_max,
-                                                                       const float *__restrict__ edge_sum, GatDrop dr,
-                                                                       const float *__restrict__ dO,
-                                                                       float *__restrict__ grad_edge,
-                                                                       float *__restrict__ grad_row) {
-  constexpr int G = C::G;
-  const int head = blockIdx.y, h = g.h, f = g.f;
-  const size_t hf = (size_t)h * f, hoff = (size_t)head * f;
-  const int gl = threadIdx.x % G;
-  const int ngroups = gridDim.x * (kBlock / G);
-  float *G_h = grad_edge + (size_t)head * g.nnz;
-  for (int r = blockIdx.x * (kBlock / G) + threadIdx.x / G; r < g.m; r += ngroups) {
-    const int lb = g.row_ptr[r], deg = g.row_ptr[r + 1] - lb;
-    float rs = 0.f;
-    if (deg > 0) {
-      const float ar = attn_row[(size_t)r * h + head];
-      const float mx = edge_max[(size_t)r * h + head], inv = 1.f / edge_sum[(size_t)r * h + head];
-      Frag<C> go;
-      frag_load<C>(go, dO + (size_t)r * hf + hoff, f, gl);
-      float t = 0.f;
-      for (int e = 0; e < deg; ++e) {  // g_e parked in grad_edge (every lane of the group holds the same value)
-        const int c = g.col_ind[lb + e];
-        Frag<C> x;
-        frag_load<C>(x, X + (size_t)c * hf + hoff, f, gl);
-        const float dp = lanes_sum<G>(frag_dot<C>(go, x));
-        const bool keep = dr.mask ? dr.mask[(size_t)(lb + e) * h + head] > dr.drop : true;
-        const float ge = keep ? dp * dr.scale : 0.f;
-        const float p = fast_exp(leaky_relu(ar + attn_col[(size_t)c * h + head], slope) - mx) * inv;
+        const int e = lb + t0 + lane;
+        const float pre = ar + a.attn_col[a.nh(c)];
+        const float p = fast_exp(leaky_relu(pre, a.slope) - mx) * inv;
+        const float ge = a.keep(e) ? sw[lane] * a.dr.scale : 0.f;
         t = fmaf(p, ge, t);
-        if (gl == 0) G_h[lb + e] = ge;
+        p_keep = p;
+        g_keep = ge;
+        lr_keep = pre > 0.f ? 1.f : a.slope;
+        if (deg > kWave) a.G_h[e] = ge;
       }
-      for (int e = 0; e < deg; ++e) {
-        const float pre = ar + attn_col[(size_t)g.col_ind[lb + e] * h + head];
-        const float p = fast_exp(leaky_relu(pre, slope) - mx) * inv;
-        // lane 0 re-reads what it parked; the other lanes only need rs, which lane 0 writes
-        const float ge = (gl == 0) ? p * (G_h[lb + e] - t) * (pre > 0.f ? 1.f : slope) : 0.f;
-        if (gl == 0) G_h[lb + e] = ge;
+      wave_sync();
+    }
+    t = lanes_sum<kWave>(t);
+    if (deg <= kWave) {
+      float ge = 0.f;
+      if (lane < deg) {
+        ge = p_keep * (g_keep - t) * lr_keep;
+        a.G_h[lb + lane] = ge;
+      }
+      rs = lanes_sum<kWave>(ge);
+    } else {
+      for (int e = lb + lane; e < lb + deg; e += kWave) {
+        const float pre = ar + a.attn_col[a.nh(a.col_ind[e])];
+        const float p = fast_exp(leaky_relu(pre, a.slope) - mx) * inv;
+        const float ge = p * (a.G_h[e] - t) * (pre > 0.f ? 1.f : a.slope);  // this lane parked G_h[e] in sweep 1
+        a.G_h[e] = ge;
         rs += ge;
       }
+      rs = lanes_sum<kWave>(rs);
     }
-    if (gl == 0) grad_row[(size_t)r * h + head] = rs;
+  }
+  if (lane == 0) a.grad_row[a.nh(r)] = rs;
+}
+
+template <class C>
+__device__ __forceinline__ void gat_bwd_col_wave(const GatTrain &a, int j, int lane, float *sw, int *sc) {
+  const int gid = lane / C::G, gl = lane % C::G;
+  const int lb = a.col_ptr[j], n = a.col_ptr[j + 1] - lb;
+  const float ac = a.attn_col[a.nh(j)];
+  Frag<C> acc;
+  frag_zero<C>(acc);
+  float gs = 0.f;
+  for (int t0 = 0; t0 < n; t0 += kWave) {
+    const int nt = min(kWave, n - t0);
+    float w = 0.f;
+    int i = 0;
+    if (lane < nt) {
+      i = a.row_ind[lb + t0 + lane];
+      const int e = a.permute[lb + t0 + lane];
+      const float p = fast_exp(leaky_relu(a.attn_row[a.nh(i)] + ac, a.slope) - a.edge_max[a.nh(i)]) / a.edge_sum[a.nh(i)];
+      w = a.keep(e) ? p * a.dr.scale : 0.f;
+      gs += a.G_h[e];
+    }
+    sw[lane] = w;
+    sc[lane] = i;
+    wave_sync();
+    spmm_accum<C>(acc, sw, sc, nt, a.dOh, a.hf, a.f, gid, gl);
+    wave_sync();
+  }
+  frag_reduce_groups<C>(acc);
+  if (gid == 0) frag_store_scaled<C>(acc, 1.f, a.gfeath + (size_t)j * a.hf, a.f, gl);
+  gs = lanes_sum<kWave>(gs);
+  if (lane == 0) a.grad_col[a.nh(j)] = gs;
+}
+
+// ======================================================================================================================
+// a group of G lanes (one feature row wide) per row: low-degree graphs (molecules, peptides: ~2 edges per row), where a
+// wave per row wastes most of its lanes.  As in gt_lowdeg.hip: EPW rows per wave, everything in registers, loops to
+// each group's own degree.  The logits are scalars, so the row statistics are exact two-sweep values.
+// ======================================================================================================================
+template <class C>
+__device__ __forceinline__ void gat_fwd_row_group(const GatTrain &a, int r, int gl) {
+  const int lb = a.row_ptr[r], deg = a.row_ptr[r + 1] - lb;
+  const float ar = a.attn_row[a.nh(r)];
+  float mx = -INFINITY;
+  for (int e = 0; e < deg; ++e) mx = fmaxf(mx, leaky_relu(ar + a.attn_col[a.nh(a.col_ind[lb + e])], a.slope));
+  Frag<C> acc;
+  frag_zero<C>(acc);
+  float sum = 0.f;
+  for (int e = 0; e < deg; ++e) {
+    const int c = a.col_ind[lb + e];
+    const float p = fast_exp(leaky_relu(ar + a.attn_col[a.nh(c)], a.slope) - mx);
+    sum += p;  // the row sum counts every edge, dropped or not
+    Frag<C> x;
+    frag_load<C>(x, a.Xh + (size_t)c * a.hf, a.f, gl);
+    frag_fma<C>(acc, a.keep(lb + e) ? p : 0.f, x);
+  }
+  frag_store_scaled<C>(acc, sum != 0.f ? a.dr.scale / sum : 0.f, a.outh + (size_t)r * a.hf, a.f, gl);
+  if (gl == 0) {
+    a.edge_max[a.nh(r)] = deg > 0 ? mx : -1e38f;
+    a.edge_sum[a.nh(r)] = sum;
   }
 }
 
 template <class C>
-__global__ __launch_bounds__(kBlock) void gat_rowgroup_bwd_cols_kernel(
-    Csr g, const int *__restrict__ col_ptr, const int *__restrict__ row_ind, const int *__restrict__ permute,
-    const float *__restrict__ attn_row, const float *__restrict__ attn_col, float slope,
-    const float *__restrict__ edge_max, const float *__restrict__ edge_sum, GatDrop dr,
-    const float *__restrict__ grad_edge, const float *__restrict__ dO, float *__restrict__ grad_feat,
-    float *__restrict__ grad_col) {
-  constexpr int G = C::G;
-  const int head = blockIdx.y, h = g.h, f = g.f;
-  const size_t hf = (size_t)h * f, hoff = (size_t)head * f;
-  const int gl = threadIdx.x % G;
-  const int ngroups = gridDim.x * (kBlock / G);
-  const float *G_h = grad_edge + (size_t)head * g.nnz;
-  for (int j = blockIdx.x * (kBlock / G) + threadIdx.x / G; j < g.m; j += ngroups) {
-    const int lb = col_ptr[j], n = col_ptr[j + 1] - lb;
-    const float ac = attn_col[(size_t)j * h + head];
-    Frag<C> acc;
-    frag_zero<C>(acc);
-    float gs = 0.f;
-    for (int t = 0; t < n; ++t) {
-      const int i = row_ind[lb + t], e = permute[lb + t];
-      const float p = fast_exp(leaky_relu(attn_row[(size_t)i * h + head] + ac, slope) - edge_max[(size_t)i * h + head]) /
-                      edge_sum[(size_t)i * h + head];
-      const bool keep = dr.mask ? dr.mask[(size_t)e * h + head] > dr.drop : true;
-      Frag<C> go;
-      frag_load<C>(go, dO + (size_t)i * hf + hoff, f, gl);
-      frag_fma<C>(acc, keep ? p * dr.scale : 0.f, go);
-      gs += G_h[e];
+__device__ __forceinline__ void gat_bwd_row_group(const GatTrain &a, int r, int gl) {
+  const int lb = a.row_ptr[r], deg = a.row_ptr[r + 1] - lb;
+  float rs = 0.f;
+  if (deg > 0) {
+    const float ar = a.attn_row[a.nh(r)];
+    const float mx = a.edge_max[a.nh(r)], inv = 1.f / a.edge_sum[a.nh(r)];
+    Frag<C> go;
+    frag_load<C>(go, a.dOh + (size_t)r * a.hf, a.f, gl);
+    float t = 0.f;
+    for (int e = 0; e < deg; ++e) {  // g_e parked in grad_edge by lane 0 (every lane of the group holds the same value)
+      const int c = a.col_ind[lb + e];
+      Frag<C> x;
+      frag_load<C>(x, a.Xh + (size_t)c * a.hf, a.f, gl);
+      const float dp = lanes_sum<C::G>(frag_dot<C>(go, x));
+      const float ge = a.keep(lb + e) ? dp * a.dr.scale : 0.f;
+      t = fmaf(fast_exp(leaky_relu(ar + a.attn_col[a.nh(c)], a.slope) - mx) * inv, ge, t);
+      if (gl == 0) a.G_h[lb + e] = ge;
     }
-    frag_store_scaled<C>(acc, 1.f, grad_feat + (size_t)j * hf + hoff, f, gl);
-    if (gl == 0) grad_col[(size_t)j * h + head] = gs;
+    if (gl == 0)  // lane 0 re-reads what it parked; only it needs the row sum
+      for (int e = 0; e < deg; ++e) {
+        const float pre = ar + a.attn_col[a.nh(a.col_ind[lb + e])];
+        const float ge = fast_exp(leaky_relu(pre, a.slope) - mx) * inv * (a.G_h[lb + e] - t) * (pre > 0.f ? 1.f : a.slope);
+        a.G_h[lb + e] = ge;
+        rs += ge;
+      }
+  }
+  if (gl == 0) a.grad_row[a.nh(r)] = rs;
+}
+
+template <class C>
+__device__ __forceinline__ void gat_bwd_col_group(const GatTrain &a, int j, int gl) {
+  const int lb = a.col_ptr[j], n = a.col_ptr[j + 1] - lb;
+  const float ac = a.attn_col[a.nh(j)];
+  Frag<C> acc;
+  frag_zero<C>(acc);
+  float gs = 0.f;
+  for (int t = 0; t < n; ++t) {
+    const int i = a.row_ind[lb + t], e = a.permute[lb + t];
+    const float p = fast_exp(leaky_relu(a.attn_row[a.nh(i)] + ac, a.slope) - a.edge_max[a.nh(i)]) / a.edge_sum[a.nh(i)];
+    Frag<C> go;
+    frag_load<C>(go, a.dOh + (size_t)i * a.hf, a.f, gl);
+    frag_fma<C>(acc, a.keep(e) ? p * a.dr.scale : 0.f, go);
+    gs += a.G_h[e];
+  }
+  frag_store_scaled<C>(acc, 1.f, a.gfeath + (size_t)j * a.hf, a.f, gl);
+  if (gl == 0) a.grad_col[a.nh(j)] = gs;
+}
+
+// ======================================================================================================================
+// kernels.  PASS: 0 forward, 1 backward CSR pass, 2 backward CSC pass.
+// ======================================================================================================================
+template <class C, int PASS>
+__device__ __forceinline__ void gat_wave_pass(const GatTrain &a, int r, int lane, float *sw, int *sc) {
+  if constexpr (PASS == 0) gat_fwd_row_wave<C>(a, r, lane, sw, sc);
+  else if constexpr (PASS == 1) gat_bwd_row_wave<C>(a, r, lane, sw, sc);
+  else gat_bwd_col_wave<C>(a, r, lane, sw, sc);
+}
+template <class C, int PASS>
+__device__ __forceinline__ void gat_group_pass(const GatTrain &a, int r, int gl) {
+  if constexpr (PASS == 0) gat_fwd_row_group<C>(a, r, gl);
+  else if constexpr (PASS == 1) gat_bwd_row_group<C>(a, r, gl);
+  else gat_bwd_col_group<C>(a, r, gl);
+}
+
+// general: a wave per row / column over the whole graph (grid-strided) or over the ranges of `rl`
+template <class C, int PASS>
+__global__ __launch_bounds__(kBlock) void gat_train_wave_kernel(GatTrain a, RowLists rl) {
+  __shared__ __attribute__((aligned(16))) float lds[kWavesPerBlock * kScratchFloatsPerWave];
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+  float *sw = lds + wave * kScratchFloatsPerWave;
+  int *sc = reinterpret_cast<int *>(sw + kWave);
+  a.head = blockIdx.y;
+  a.Xh += (size_t)a.head * a.f;
+  a.dOh += (size_t)a.head * a.f;
+  if (a.outh) a.outh += (size_t)a.head * a.f;
+  if (a.gfeath) a.gfeath += (size_t)a.head * a.f;
+  if (a.G_h) a.G_h += (size_t)a.head * a.nnz;
+  int beg, end, step;
+  row_span(rl, a.m, wave, beg, end, step);  // (CSC pass: closed ranges, a range's columns are its rows)
+  for (int r = beg; r < end; r += step) gat_wave_pass<C, PASS>(a, r, lane, sw, sc);
+}
+
+// low-degree graphs: a workgroup takes blocks of kBlock / G consecutive rows, one lane group per row -- unless the
+// block holds a row (column) of more than kGroupMaxDegree entries, which a single lane group would walk serially
+// while the rest of its wave waits (a hub of a citation graph): such a block is given to the wave-per-row routine.
+constexpr int kGroupMaxDegree = 24;
+template <class C, int PASS>
+__global__ __launch_bounds__(kBlock) void gat_train_group_kernel(GatTrain a) {
+  __shared__ __attribute__((aligned(16))) float lds[kWavesPerBlock * kScratchFloatsPerWave];
+  constexpr int R = kBlock / C::G;  // rows per block
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+  float *sw = lds + wave * kScratchFloatsPerWave;
+  int *sc = reinterpret_cast<int *>(sw + kWave);
+  a.head = blockIdx.y;
+  a.Xh += (size_t)a.head * a.f;
+  a.dOh += (size_t)a.head * a.f;
+  if (a.outh) a.outh += (size_t)a.head * a.f;
+  if (a.gfeath) a.gfeath += (size_t)a.head * a.f;
+  if (a.G_h) a.G_h += (size_t)a.head * a.nnz;
+  const int *ptr = PASS == 2 ? a.col_ptr : a.row_ptr;
+  for (int b0 = blockIdx.x * R; b0 < a.m; b0 += gridDim.x * R) {  // (uniform trip count: the barrier below is safe)
+    const int r = b0 + threadIdx.x / C::G;
+    const int deg = r < a.m ? ptr[r + 1] - ptr[r] : 0;
+    if (__syncthreads_or(deg > kGroupMaxDegree)) {
+      for (int rr = b0 + wave; rr < min(a.m, b0 + R); rr += kWavesPerBlock) gat_wave_pass<C, PASS>(a, rr, lane, sw, sc);
+    } else if (r < a.m) {
+      gat_group_pass<C, PASS>(a, r, threadIdx.x % C::G);
+    }
   }
 }
 
@@ -387,21 +365,17 @@ static bool lowdeg_enabled() {
   static const bool on = [] { const char *e = getenv("DFGNN_LOWDEG"); return !e || atoi(e) != 0; }();
   return on;
 }
-static inline bool use_rowgroup(const Csr &g, const Plan *rest) {
-  return !rest && lowdeg_enabled() && low_degree(g.m, g.nnz);
-}
 
-static dim3 rowgroup_grid(const Csr &g, int G) {
+static dim3 group_grid(int m, int h, int G) {
   const long per = kBlock / G;
-  long blocks = ((long)g.m + per - 1) / per;
+  long blocks = ((long)m + per - 1) / per;
   if (blocks > 16384) blocks = 16384;
-  return dim3((unsigned)(blocks < 1 ? 1 : blocks), g.h);
+  return dim3((unsigned)(blocks < 1 ? 1 : blocks), h);
 }
-
-static inline int row_grid(int m, const RowLists &rl) {
-  if (rl.na + rl.nb > 0) return rl.na + rl.nb;
+static dim3 wave_grid(int m, int h, const RowLists &rl) {
+  if (rl.na + rl.nb > 0) return dim3(rl.na + rl.nb, h);
   const long want = ((long)m + kWavesPerBlock - 1) / kWavesPerBlock;
-  return (int)(want > (1 << 20) ? (1 << 20) : want);
+  return dim3((unsigned)(want > (1 << 20) ? (1 << 20) : want), h);
 }
 // the ranges of a plan the matrix-core kernels do not serve (none: the whole graph)
 static inline RowLists rest_of(const Plan *p) {
@@ -409,62 +383,54 @@ static inline RowLists rest_of(const Plan *p) {
   return RowLists{p->fit() + 2 * (size_t)p->num_dense, p->spill(), p->num_fit - p->num_dense, p->num_spill};
 }
 
+template <int PASS>
+static int launch_gat_train_pass(const GatTrain &a, bool v4, const Plan *rest, hipStream_t s) {
+  const RowLists rl = rest_of(rest);
+  const bool groups = !rest && lowdeg_enabled() && low_degree(a.m, a.nnz);
+  return dispatch_cfg(a.f, v4, [&](auto cfg) {
+    using C = decltype(cfg);
+    if (groups) gat_train_group_kernel<C, PASS><<<group_grid(a.m, a.h, C::G), kBlock, 0, s>>>(a);
+    else gat_train_wave_kernel<C, PASS><<<wave_grid(a.m, a.h, rl), kBlock, 0, s>>>(a, rl);
+    return launch_status();
+  });
+}
+
+static GatTrain gat_args(const Csr &g, const float *attn_row, const float *attn_col, float slope,
+                         const float *edge_mask, float attn_drop) {
+  GatTrain a{};
+  a.m = g.m; a.nnz = g.nnz; a.h = g.h; a.f = g.f; a.hf = (size_t)g.h * g.f;
+  a.row_ptr = g.row_ptr; a.col_ind = g.col_ind;
+  a.attn_row = attn_row; a.attn_col = attn_col; a.slope = slope;
+  a.dr = GatDrop{edge_mask, attn_drop, edge_mask ? 1.f / (1.f - attn_drop) : 1.f};
+  return a;
+}
+
 int launch_gat_train_fwd(const Csr &g, const float *attn_row, const float *attn_col, float slope, const float *X,
                          const float *edge_mask, float attn_drop, float *edge_max, float *edge_sum, float *out,
                          hipStream_t s, const Plan *rest) {
-  const RowLists rl = rest_of(rest);
-  const dim3 grid(row_grid(g.m, rl), g.h);
-  const GatDrop dr{edge_mask, attn_drop, edge_mask ? 1.f / (1.f - attn_drop) : 1.f};
-  const bool v4 = (g.f % 4 == 0) && aligned16(X) && aligned16(out);
-  return dispatch_cfg(g.f, v4, [&](auto cfg) {
-    using C = decltype(cfg);
-    if (use_rowgroup(g, rest))
-      gat_rowgroup_fwd_kernel<C><<<rowgroup_grid(g, C::G), kBlock, 0, s>>>(g, attn_row, attn_col, slope, X, dr, edge_max,
-                                                                          edge_sum, out);
-    else
-      gat_train_fwd_kernel<C><<<grid, kBlock, 0, s>>>(g, attn_row, attn_col, slope, X, dr, edge_max, edge_sum, out, rl);
-    return launch_status();
-  });
+  GatTrain a = gat_args(g, attn_row, attn_col, slope, edge_mask, attn_drop);
+  a.Xh = X; a.dOh = X; a.outh = out; a.edge_max = edge_max; a.edge_sum = edge_sum;
+  return launch_gat_train_pass<0>(a, (g.f % 4 == 0) && aligned16(X) && aligned16(out), rest, s);
 }
 
 int launch_gat_bwd_rows(const Csr &g, const float *attn_row, const float *attn_col, float slope, const float *X,
                         const float *edge_max, const float *edge_sum, const float *edge_mask, float attn_drop,
                         const float *grad_out, float *grad_edge, float *grad_row, hipStream_t s, const Plan *rest) {
-  const RowLists rl = rest_of(rest);
-  const dim3 grid(row_grid(g.m, rl), g.h);
-  const GatDrop dr{edge_mask, attn_drop, edge_mask ? 1.f / (1.f - attn_drop) : 1.f};
-  const bool v4 = (g.f % 4 == 0) && aligned16(X) && aligned16(grad_out);
-  return dispatch_cfg(g.f, v4, [&](auto cfg) {
-    using C = decltype(cfg);
-    if (use_rowgroup(g, rest))
-      gat_rowgroup_bwd_rows_kernel<C><<<rowgroup_grid(g, C::G), kBlock, 0, s>>>(g, attn_row, attn_col, slope, X, edge_max,
-                                                                               edge_sum, dr, grad_out, grad_edge, grad_row);
-    else
-      gat_bwd_rows_kernel<C><<<grid, kBlock, 0, s>>>(g, attn_row, attn_col, slope, X, edge_max, edge_sum, dr, grad_out,
-                                                     grad_edge, grad_row, rl);
-    return launch_status();
-  });
+  GatTrain a = gat_args(g, attn_row, attn_col, slope, edge_mask, attn_drop);
+  a.Xh = X; a.dOh = grad_out; a.G_h = grad_edge; a.grad_row = grad_row;
+  a.edge_max = const_cast<float *>(edge_max); a.edge_sum = const_cast<float *>(edge_sum);
+  return launch_gat_train_pass<1>(a, (g.f % 4 == 0) && aligned16(X) && aligned16(grad_out), rest, s);
 }
 
 int launch_gat_bwd_cols(const Csr &g, const int *col_ptr, const int *row_ind, const int *permute,
                         const float *attn_row, const float *attn_col, float slope, const float *edge_max,
                         const float *edge_sum, const float *edge_mask, float attn_drop, const float *grad_edge,
                         const float *grad_out, float *grad_feat, float *grad_col, hipStream_t s, const Plan *rest) {
-  const RowLists rl = rest_of(rest);
-  const dim3 grid(row_grid(g.m, rl), g.h);
-  const GatDrop dr{edge_mask, attn_drop, edge_mask ? 1.f / (1.f - attn_drop) : 1.f};
-  const bool v4 = (g.f % 4 == 0) && aligned16(grad_out) && aligned16(grad_feat);
-  return dispatch_cfg(g.f, v4, [&](auto cfg) {
-    using C = decltype(cfg);
-    if (use_rowgroup(g, rest))
-      gat_rowgroup_bwd_cols_kernel<C><<<rowgroup_grid(g, C::G), kBlock, 0, s>>>(
-          g, col_ptr, row_ind, permute, attn_row, attn_col, slope, edge_max, edge_sum, dr, grad_edge, grad_out, grad_feat,
-          grad_col);
-    else
-      gat_bwd_cols_kernel<C><<<grid, kBlock, 0, s>>>(g, col_ptr, row_ind, permute, attn_row, attn_col, slope, edge_max,
-                                                     edge_sum, dr, grad_edge, grad_out, grad_feat, grad_col, rl);
-    return launch_status();
-  });
+  GatTrain a = gat_args(g, attn_row, attn_col, slope, edge_mask, attn_drop);
+  a.col_ptr = col_ptr; a.row_ind = row_ind; a.permute = permute;
+  a.Xh = grad_out; a.dOh = grad_out; a.gfeath = grad_feat; a.G_h = const_cast<float *>(grad_edge); a.grad_col = grad_col;
+  a.edge_max = const_cast<float *>(edge_max); a.edge_sum = const_cast<float *>(edge_sum);
+  return launch_gat_train_pass<2>(a, (g.f % 4 == 0) && aligned16(grad_out) && aligned16(grad_feat), rest, s);
 }
 
 }  // namespace dfgnn
