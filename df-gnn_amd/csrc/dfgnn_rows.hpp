@@ -161,4 +161,106 @@ __device__ __forceinline__ void gat_row_online(int lb, int deg, const int *__res
   if (gid == 0) frag_store_scaled<C>(acc, inv, out_row, f, gl);
 }
 
+// GT backward, CSR pass for one row by one wave, any degree: dP_e = <dO_r, V_c> in 64-edge tiles (parked in dS_h
+// between the two sweeps), dS_e = P_e (dP_e - sum_row P dP) -> dS_h, dQ_r = sum_e dS_e val_e K_c.  Pointers are offset
+// to the head; P_h / dS_h are the head's [nnz] arrays.
+template <class C>
+__device__ __forceinline__ void gt_bwd_row_online(int r, int lb, int deg, const int *__restrict__ col_ind,
+                                                  const float *__restrict__ val, const float *__restrict__ Kh,
+                                                  const float *__restrict__ Vh, const float *__restrict__ dOh,
+                                                  const float *__restrict__ P_h, float *__restrict__ dS_h, size_t hf,
+                                                  int f, float *sw, int *sc, float *__restrict__ dQh, int lane) {
+  const int gid = lane / C::G, gl = lane % C::G;
+  Frag<C> go;
+  frag_load<C>(go, dOh + (size_t)r * hf, f, gl);
+  float t = 0.f;
+  for (int t0 = 0; t0 < deg; t0 += kWave) {
+    const int nt = min(kWave, deg - t0);
+    sc[lane] = (lane < nt) ? col_ind[lb + t0 + lane] : 0;
+    wave_sync();
+    for (int e = gid; e < nt; e += C::EPW) {
+      Frag<C> v;
+      frag_load<C>(v, Vh + (size_t)sc[e] * hf, f, gl);
+      const float d = lanes_sum<C::G>(frag_dot<C>(go, v));
+      if (gl == 0) sw[e] = d;
+    }
+    wave_sync();
+    if (lane < nt) {
+      const float dp = sw[lane];
+      dS_h[lb + t0 + lane] = dp;
+      t = fmaf(dp, P_h[lb + t0 + lane], t);
+    }
+    wave_sync();
+  }
+  t = lanes_sum<kWave>(t);
+  Frag<C> acc;
+  frag_zero<C>(acc);
+  for (int t0 = 0; t0 < deg; t0 += kWave) {
+    const int nt = min(kWave, deg - t0);
+    float w = 0.f;
+    int c = 0;
+    if (lane < nt) {
+      const int e = lb + t0 + lane;
+      const float ds = P_h[e] * (dS_h[e] - t);  // same lane wrote dS_h[e] above
+      dS_h[e] = ds;
+      w = val ? ds * val[e] : ds;
+      c = col_ind[e];
+    }
+    sw[lane] = w;
+    sc[lane] = c;
+    wave_sync();
+    spmm_accum<C>(acc, sw, sc, nt, Kh, hf, f, gid, gl);
+    wave_sync();
+  }
+  frag_reduce_groups<C>(acc);
+  if (gid == 0) frag_store_scaled<C>(acc, 1.f, dQh + (size_t)r * hf, f, gl);
+}
+
+// GT backward, CSC pass for one column by one wave: dV_j = sum P_e dO_i, dK_j = sum dS_e val_e Q_i over the column's
+// CSC entries (lb .. lb + n), two entries in flight per lane group.
+template <class C>
+__device__ __forceinline__ void gt_bwd_col_wave(int j, int lb, int n, const int *__restrict__ row_ind,
+                                                const int *__restrict__ val_idx, const float *__restrict__ val,
+                                                const float *__restrict__ Qh, const float *__restrict__ dOh,
+                                                const float *__restrict__ P_h, const float *__restrict__ dS_h, size_t hf,
+                                                int f, float *__restrict__ dKh, float *__restrict__ dVh, int lane) {
+  const int gid = lane / C::G, gl = lane % C::G;
+  Frag<C> aK, aV;
+  frag_zero<C>(aK);
+  frag_zero<C>(aV);
+  int t = gid;
+  for (; t + C::EPW < n; t += 2 * C::EPW) {
+    const int ea = val_idx[lb + t], eb = val_idx[lb + t + C::EPW];
+    const int ia = row_ind[lb + t], ib = row_ind[lb + t + C::EPW];
+    const float pa = P_h[ea], pb = P_h[eb];
+    const float sa = val ? dS_h[ea] * val[ea] : dS_h[ea];
+    const float sb = val ? dS_h[eb] * val[eb] : dS_h[eb];
+    Frag<C> ga, gb, qa, qb;
+    frag_load<C>(ga, dOh + (size_t)ia * hf, f, gl);
+    frag_load<C>(qa, Qh + (size_t)ia * hf, f, gl);
+    frag_load<C>(gb, dOh + (size_t)ib * hf, f, gl);
+    frag_load<C>(qb, Qh + (size_t)ib * hf, f, gl);
+    frag_fma<C>(aV, pa, ga);
+    frag_fma<C>(aK, sa, qa);
+    frag_fma<C>(aV, pb, gb);
+    frag_fma<C>(aK, sb, qb);
+  }
+  for (; t < n; t += C::EPW) {
+    const int ea = val_idx[lb + t], ia = row_ind[lb + t];
+    const float pa = P_h[ea];
+    const float sa = val ? dS_h[ea] * val[ea] : dS_h[ea];
+    Frag<C> ga, qa;
+    frag_load<C>(ga, dOh + (size_t)ia * hf, f, gl);
+    frag_load<C>(qa, Qh + (size_t)ia * hf, f, gl);
+    frag_fma<C>(aV, pa, ga);
+    frag_fma<C>(aK, sa, qa);
+  }
+  frag_reduce_groups<C>(aK);
+  frag_reduce_groups<C>(aV);
+  if (gid == 0) {
+    frag_store_scaled<C>(aK, 1.f, dKh + (size_t)j * hf, f, gl);
+    frag_store_scaled<C>(aV, 1.f, dVh + (size_t)j * hf, f, gl);
+  }
+}
+
 }  // namespace dfgnn

@@ -332,9 +332,9 @@ __global__ __launch_bounds__(kBlock) void gat_train_wave_kernel(GatTrain a, RowL
 }
 
 // low-degree graphs: a workgroup takes blocks of kBlock / G consecutive rows, one lane group per row -- unless the
-// block holds a row (column) of more than kGroupMaxDegree entries, which a single lane group would walk serially
+// block holds a row (column) of more than kGatGroupMaxDegree entries, which a single lane group would walk serially
 // while the rest of its wave waits (a hub of a citation graph): such a block is given to the wave-per-row routine.
-constexpr int kGroupMaxDegree = 24;
+constexpr int kGatGroupMaxDegree = 24;
 template <class C, int PASS>
 __global__ __launch_bounds__(kBlock) void gat_train_group_kernel(GatTrain a) {
   __shared__ __attribute__((aligned(16))) float lds[kWavesPerBlock * kScratchFloatsPerWave];
@@ -352,7 +352,7 @@ __global__ __launch_bounds__(kBlock) void gat_train_group_kernel(GatTrain a) {
   for (int b0 = blockIdx.x * R; b0 < a.m; b0 += gridDim.x * R) {  // (uniform trip count: the barrier below is safe)
     const int r = b0 + threadIdx.x / C::G;
     const int deg = r < a.m ? ptr[r + 1] - ptr[r] : 0;
-    if (__syncthreads_or(deg > kGroupMaxDegree)) {
+    if (__syncthreads_or(deg > kGatGroupMaxDegree)) {
       for (int rr = b0 + wave; rr < min(a.m, b0 + R); rr += kWavesPerBlock) gat_wave_pass<C, PASS>(a, rr, lane, sw, sc);
     } else if (r < a.m) {
       gat_group_pass<C, PASS>(a, r, threadIdx.x % C::G);

@@ -69,49 +69,7 @@ __global__ __launch_bounds__(kBlock) void gt_bwd_rows_kernel(Csr g, const float 
     // heavy rows: 64-edge tiles, dP parked in grad_edge between the two sweeps
     for (int r = r0 + wave; r < r1; r += kWavesPerBlock) {
       const int lb = g.row_ptr[r], deg = g.row_ptr[r + 1] - lb;
-      Frag<C> go;
-      frag_load<C>(go, dOh + (size_t)r * hf, f, gl);
-      float t = 0.f;
-      for (int t0 = 0; t0 < deg; t0 += kWave) {
-        const int nt = min(kWave, deg - t0);
-        sc[lane] = (lane < nt) ? g.col_ind[lb + t0 + lane] : 0;
-        wave_sync();
-        for (int e = gid; e < nt; e += C::EPW) {
-          Frag<C> v;
-          frag_load<C>(v, Vh + (size_t)sc[e] * hf, f, gl);
-          const float d = lanes_sum<C::G>(frag_dot<C>(go, v));
-          if (gl == 0) sw[e] = d;
-        }
-        wave_sync();
-        if (lane < nt) {
-          const float dp = sw[lane];
-          dS_h[lb + t0 + lane] = dp;
-          t = fmaf(dp, P_h[lb + t0 + lane], t);
-        }
-        wave_sync();
-      }
-      t = lanes_sum<kWave>(t);
-      Frag<C> acc;
-      frag_zero<C>(acc);
-      for (int t0 = 0; t0 < deg; t0 += kWave) {
-        const int nt = min(kWave, deg - t0);
-        float w = 0.f;
-        int c = 0;
-        if (lane < nt) {
-          const int e = lb + t0 + lane;
-          const float ds = P_h[e] * (dS_h[e] - t);  // same lane wrote dS_h[e] above
-          dS_h[e] = ds;
-          w = g.val ? ds * g.val[e] : ds;
-          c = g.col_ind[e];
-        }
-        sw[lane] = w;
-        sc[lane] = c;
-        wave_sync();
-        spmm_accum<C>(acc, sw, sc, nt, Kh, hf, f, gid, gl);
-        wave_sync();
-      }
-      frag_reduce_groups<C>(acc);
-      if (gid == 0) frag_store_scaled<C>(acc, 1.f, dQh + (size_t)r * hf, f, gl);
+      gt_bwd_row_online<C>(r, lb, deg, g.col_ind, g.val, Kh, Vh, dOh, P_h, dS_h, hf, f, sw, sc, dQh, lane);
     }
   }
 }
@@ -132,49 +90,14 @@ __global__ __launch_bounds__(kBlock) void gt_bwd_cols_kernel(Csr g, const int *_
   const int f = g.f;
   const float *Qh = Q + (size_t)head * f, *dOh = dO + (size_t)head * f;
   const float *P_h = attn_edge + (size_t)head * g.nnz, *dS_h = grad_edge + (size_t)head * g.nnz;
-  const int gid = lane / C::G, gl = lane % C::G;
   // columns of this workgroup: grid-strided over all columns, or (with a block plan) one spill chunk
   const int jbeg = chunks ? chunks[2 * blockIdx.x] + wave : blockIdx.x * kWavesPerBlock + wave;
   const int jend = chunks ? chunks[2 * blockIdx.x + 1] : g.m;
   const int jstep = chunks ? kWavesPerBlock : gridDim.x * kWavesPerBlock;
   for (int j = jbeg; j < jend; j += jstep) {
     const int lb = col_ptr[j], n = col_ptr[j + 1] - lb;
-    Frag<C> aK, aV;
-    frag_zero<C>(aK);
-    frag_zero<C>(aV);
-    int t = gid;
-    for (; t + C::EPW < n; t += 2 * C::EPW) {
-      const int ea = val_idx[lb + t], eb = val_idx[lb + t + C::EPW];
-      const int ia = row_ind[lb + t], ib = row_ind[lb + t + C::EPW];
-      const float pa = P_h[ea], pb = P_h[eb];
-      const float sa = g.val ? dS_h[ea] * g.val[ea] : dS_h[ea];
-      const float sb = g.val ? dS_h[eb] * g.val[eb] : dS_h[eb];
-      Frag<C> ga, gb, qa, qb;
-      frag_load<C>(ga, dOh + (size_t)ia * hf, f, gl);
-      frag_load<C>(qa, Qh + (size_t)ia * hf, f, gl);
-      frag_load<C>(gb, dOh + (size_t)ib * hf, f, gl);
-      frag_load<C>(qb, Qh + (size_t)ib * hf, f, gl);
-      frag_fma<C>(aV, pa, ga);
-      frag_fma<C>(aK, sa, qa);
-      frag_fma<C>(aV, pb, gb);
-      frag_fma<C>(aK, sb, qb);
-    }
-    for (; t < n; t += C::EPW) {
-      const int ea = val_idx[lb + t], ia = row_ind[lb + t];
-      const float pa = P_h[ea];
-      const float sa = g.val ? dS_h[ea] * g.val[ea] : dS_h[ea];
-      Frag<C> ga, qa;
-      frag_load<C>(ga, dOh + (size_t)ia * hf, f, gl);
-      frag_load<C>(qa, Qh + (size_t)ia * hf, f, gl);
-      frag_fma<C>(aV, pa, ga);
-      frag_fma<C>(aK, sa, qa);
-    }
-    frag_reduce_groups<C>(aK);
-    frag_reduce_groups<C>(aV);
-    if (gid == 0) {
-      frag_store_scaled<C>(aK, 1.f, dK + (size_t)j * hf + (size_t)head * f, f, gl);
-      frag_store_scaled<C>(aV, 1.f, dV + (size_t)j * hf + (size_t)head * f, f, gl);
-    }
+    gt_bwd_col_wave<C>(j, lb, n, row_ind, val_idx, g.val, Qh, dOh, P_h, dS_h, hf, f, dK + (size_t)head * f,
+                       dV + (size_t)head * f, lane);
   }
 }
 

@@ -4,12 +4,29 @@
 // (resident kernels) is almost all fixed cost.  Here every group of G lanes (one feature row wide) owns one row:
 // a wave works on EPW = 64/G rows at once, everything stays in registers (online softmax per edge, no LDS, no
 // barriers) and the loops run to each group's own degree under the exec mask.  Selected by the C ABI when
-// nnz < kBlockMinAvgDegree * m.  Same math as fused_gt_hyper / fused_backward_kernel / spmm_backward_kernel of
+// nnz < kBlockMinAvgDegree * m.  A workgroup takes blocks of kBlock / G consecutive rows; a block that holds a row
+// (column) of more than kGroupMaxDegree entries -- the hubs of a citation graph, which one lane group would walk
+// serially while the rest of its wave waits -- is given to the wave-per-row routines of dfgnn_rows.hpp instead.  Same math as fused_gt_hyper / fused_backward_kernel / spmm_backward_kernel of
 // the reference (fused_gtconv_hyper.cu:31-163, fused_gtconv_backward.cu:40-191).
 #include "dfgnn_launch.hpp"
 #include "dfgnn_rows.hpp"
 
 namespace dfgnn {
+
+constexpr int kGroupMaxDegree = 24;
+
+// Per-wave LDS scratch (64 weights + 64 column ids) of the wave-per-row fallback.
+struct WaveScratch {
+  float *sw;
+  int *sc;
+  int lane, wave;
+};
+__device__ __forceinline__ WaveScratch wave_scratch() {
+  __shared__ __attribute__((aligned(16))) float lds_fb[kWavesPerBlock * kScratchFloatsPerWave];
+  const int wave = threadIdx.x / kWave;
+  float *sw = lds_fb + wave * kScratchFloatsPerWave;
+  return WaveScratch{sw, reinterpret_cast<int *>(sw + kWave), (int)(threadIdx.x & (kWave - 1)), wave};
+}
 
 template <class C, bool WRITE_ATTN>
 __global__ __launch_bounds__(kBlock) void gt_rowgroup_fwd_kernel(Csr g, const float *__restrict__ Q,
@@ -21,10 +38,26 @@ __global__ __launch_bounds__(kBlock) void gt_rowgroup_fwd_kernel(Csr g, const fl
   const int head = blockIdx.y, f = g.f;
   const size_t hf = (size_t)g.h * f, hoff = (size_t)head * f;
   const int gl = threadIdx.x % G;
-  const int ngroups = gridDim.x * (kBlock / G);
   float *attn_h = WRITE_ATTN ? attn_edge + (size_t)head * g.nnz : nullptr;
-  for (int r = blockIdx.x * (kBlock / G) + threadIdx.x / G; r < g.m; r += ngroups) {
-    const int lb = g.row_ptr[r], deg = g.row_ptr[r + 1] - lb;
+  constexpr int R = kBlock / G;  // rows per block
+  const WaveScratch ws = wave_scratch();
+  const int lane = ws.lane, wave = ws.wave;
+  float *sw = ws.sw;
+  int *sc = ws.sc;
+  for (int b0 = blockIdx.x * R; b0 < g.m; b0 += gridDim.x * R) {  // (uniform trip count: the barrier is safe)
+    const int r = b0 + threadIdx.x / G;
+    const int lb = r < g.m ? g.row_ptr[r] : 0, deg = r < g.m ? g.row_ptr[r + 1] - lb : 0;
+    if (__syncthreads_or(deg > kGroupMaxDegree)) {
+      for (int rr = b0 + wave; rr < min(g.m, b0 + R); rr += kWavesPerBlock) {
+        const int lbw = g.row_ptr[rr], degw = g.row_ptr[rr + 1] - lbw;
+        Frag<C> qw;
+        frag_load<C>(qw, Q + (size_t)rr * hf + hoff, f, gl);
+        gt_row_online<C, WRITE_ATTN>(lbw, degw, g.col_ind, g.val, qw, K + hoff, V + hoff, hf, f, sw, sc,
+                                     out + (size_t)rr * hf + hoff, WRITE_ATTN ? attn_h + lbw : nullptr, lane);
+      }
+      continue;
+    }
+    if (r >= g.m) continue;
     Frag<C> q, acc;
     frag_load<C>(q, Q + (size_t)r * hf + hoff, f, gl);
     frag_zero<C>(acc);
@@ -72,11 +105,25 @@ __global__ __launch_bounds__(kBlock) void gt_rowgroup_bwd_rows_kernel(Csr g, con
   const int head = blockIdx.y, f = g.f;
   const size_t hf = (size_t)g.h * f, hoff = (size_t)head * f;
   const int gl = threadIdx.x % G;
-  const int ngroups = gridDim.x * (kBlock / G);
   const float *P_h = attn_edge + (size_t)head * g.nnz;
   float *dS_h = grad_edge + (size_t)head * g.nnz;
-  for (int r = blockIdx.x * (kBlock / G) + threadIdx.x / G; r < g.m; r += ngroups) {
-    const int lb = g.row_ptr[r], deg = g.row_ptr[r + 1] - lb;
+  constexpr int R = kBlock / G;  // rows per block
+  const WaveScratch ws = wave_scratch();
+  const int lane = ws.lane, wave = ws.wave;
+  float *sw = ws.sw;
+  int *sc = ws.sc;
+  for (int b0 = blockIdx.x * R; b0 < g.m; b0 += gridDim.x * R) {
+    const int r = b0 + threadIdx.x / G;
+    const int lb = r < g.m ? g.row_ptr[r] : 0, deg = r < g.m ? g.row_ptr[r + 1] - lb : 0;
+    if (__syncthreads_or(deg > kGroupMaxDegree)) {
+      for (int rr = b0 + wave; rr < min(g.m, b0 + R); rr += kWavesPerBlock) {
+        const int lbw = g.row_ptr[rr];
+        gt_bwd_row_online<C>(rr, lbw, g.row_ptr[rr + 1] - lbw, g.col_ind, g.val, K + hoff, V + hoff, dO + hoff, P_h, dS_h,
+                             hf, f, sw, sc, dQ + hoff, lane);
+      }
+      continue;
+    }
+    if (r >= g.m) continue;
     Frag<C> go, acc;
     frag_load<C>(go, dO + (size_t)r * hf + hoff, f, gl);
     frag_zero<C>(acc);
@@ -109,10 +156,24 @@ __global__ __launch_bounds__(kBlock) void gt_rowgroup_bwd_cols_kernel(
   const int head = blockIdx.y, f = g.f;
   const size_t hf = (size_t)g.h * f, hoff = (size_t)head * f;
   const int gl = threadIdx.x % G;
-  const int ngroups = gridDim.x * (kBlock / G);
   const float *P_h = attn_edge + (size_t)head * g.nnz, *dS_h = grad_edge + (size_t)head * g.nnz;
-  for (int j = blockIdx.x * (kBlock / G) + threadIdx.x / G; j < g.m; j += ngroups) {
-    const int lb = col_ptr[j], n = col_ptr[j + 1] - lb;
+  constexpr int R = kBlock / G;  // rows per block
+  const WaveScratch ws = wave_scratch();
+  const int lane = ws.lane, wave = ws.wave;
+  float *sw = ws.sw;
+  int *sc = ws.sc;
+  for (int b0 = blockIdx.x * R; b0 < g.m; b0 += gridDim.x * R) {
+    const int j = b0 + threadIdx.x / G;
+    const int lb = j < g.m ? col_ptr[j] : 0, n = j < g.m ? col_ptr[j + 1] - lb : 0;
+    if (__syncthreads_or(n > kGroupMaxDegree)) {
+      for (int jj = b0 + wave; jj < min(g.m, b0 + R); jj += kWavesPerBlock) {
+        const int lbw = col_ptr[jj];
+        gt_bwd_col_wave<C>(jj, lbw, col_ptr[jj + 1] - lbw, row_ind, val_idx, g.val, Q + hoff, dO + hoff, P_h, dS_h, hf, f,
+                           dK + hoff, dV + hoff, lane);
+      }
+      continue;
+    }
+    if (j >= g.m) continue;
     Frag<C> aK, aV;
     frag_zero<C>(aK);
     frag_zero<C>(aV);
