@@ -13,7 +13,7 @@
 //                     replaces mhspmm_backward_kernel (:609-660) and the atomicAdd into grad_attn_col (:853): the
 //                     column sums are deterministic here.
 // gat_train_wave_kernel runs the wave form over the whole graph or over the ranges a block plan leaves to it;
-// gat_train_group_kernel runs the lane-group form and hands any 16-row block that holds a long row to the wave form.
+// gat_train_group_kernel runs the lane-group form; a wave whose rows include a long one switches to the wave form.
 //
 // Layouts as in the reference: edge_max / edge_sum / attn_row / attn_col fp32[m, h]; edge_mask fp32[nnz, h]
 // (EDGE-major, CSR order, fused_gatconv_kernel.cu:101).  grad_edge is this library's scratch, fp32[h, nnz].
@@ -331,9 +331,10 @@ __global__ __launch_bounds__(kBlock) void gat_train_wave_kernel(GatTrain a, RowL
   for (int r = beg; r < end; r += step) gat_wave_pass<C, PASS>(a, r, lane, sw, sc);
 }
 
-// low-degree graphs: a workgroup takes blocks of kBlock / G consecutive rows, one lane group per row -- unless the
-// block holds a row (column) of more than kGatGroupMaxDegree entries, which a single lane group would walk serially
-// while the rest of its wave waits (a hub of a citation graph): such a block is given to the wave-per-row routine.
+// low-degree graphs: a workgroup takes blocks of kBlock / G consecutive rows, one lane group per row -- unless a wave's
+// EPW rows include one of more than kGatGroupMaxDegree entries, which a single lane group would walk serially while the
+// rest of the wave waits (a hub of a citation graph): that wave takes its rows one at a time with the wave-per-row
+// routine (a wave-uniform choice: no barrier).
 constexpr int kGatGroupMaxDegree = 24;
 template <class C, int PASS>
 __global__ __launch_bounds__(kBlock) void gat_train_group_kernel(GatTrain a) {
@@ -349,11 +350,12 @@ __global__ __launch_bounds__(kBlock) void gat_train_group_kernel(GatTrain a) {
   if (a.gfeath) a.gfeath += (size_t)a.head * a.f;
   if (a.G_h) a.G_h += (size_t)a.head * a.nnz;
   const int *ptr = PASS == 2 ? a.col_ptr : a.row_ptr;
-  for (int b0 = blockIdx.x * R; b0 < a.m; b0 += gridDim.x * R) {  // (uniform trip count: the barrier below is safe)
+  for (int b0 = blockIdx.x * R; b0 < a.m; b0 += gridDim.x * R) {
     const int r = b0 + threadIdx.x / C::G;
     const int deg = r < a.m ? ptr[r + 1] - ptr[r] : 0;
-    if (__syncthreads_or(deg > kGatGroupMaxDegree)) {
-      for (int rr = b0 + wave; rr < min(a.m, b0 + R); rr += kWavesPerBlock) gat_wave_pass<C, PASS>(a, rr, lane, sw, sc);
+    if (__any(deg > kGatGroupMaxDegree)) {
+      for (int rr = b0 + wave * C::EPW; rr < min(a.m, b0 + (wave + 1) * C::EPW); ++rr)
+        gat_wave_pass<C, PASS>(a, rr, lane, sw, sc);
     } else if (r < a.m) {
       gat_group_pass<C, PASS>(a, r, threadIdx.x % C::G);
     }

@@ -4,9 +4,9 @@
 // (resident kernels) is almost all fixed cost.  Here every group of G lanes (one feature row wide) owns one row:
 // a wave works on EPW = 64/G rows at once, everything stays in registers (online softmax per edge, no LDS, no
 // barriers) and the loops run to each group's own degree under the exec mask.  Selected by the C ABI when
-// nnz < kBlockMinAvgDegree * m.  A workgroup takes blocks of kBlock / G consecutive rows; a block that holds a row
-// (column) of more than kGroupMaxDegree entries -- the hubs of a citation graph, which one lane group would walk
-// serially while the rest of its wave waits -- is given to the wave-per-row routines of dfgnn_rows.hpp instead.  Same math as fused_gt_hyper / fused_backward_kernel / spmm_backward_kernel of
+// nnz < kBlockMinAvgDegree * m.  A wave whose EPW rows include one of more than kGroupMaxDegree entries -- the hubs of
+// a citation graph, which one lane group would walk serially while the rest of the wave waits -- takes its rows one at
+// a time with the wave-per-row routines of dfgnn_rows.hpp instead (a wave-uniform choice: no barrier).  Same math as fused_gt_hyper / fused_backward_kernel / spmm_backward_kernel of
 // the reference (fused_gtconv_hyper.cu:31-163, fused_gtconv_backward.cu:40-191).
 #include "dfgnn_launch.hpp"
 #include "dfgnn_rows.hpp"
@@ -44,11 +44,11 @@ __global__ __launch_bounds__(kBlock) void gt_rowgroup_fwd_kernel(Csr g, const fl
   const int lane = ws.lane, wave = ws.wave;
   float *sw = ws.sw;
   int *sc = ws.sc;
-  for (int b0 = blockIdx.x * R; b0 < g.m; b0 += gridDim.x * R) {  // (uniform trip count: the barrier is safe)
+  for (int b0 = blockIdx.x * R; b0 < g.m; b0 += gridDim.x * R) {
     const int r = b0 + threadIdx.x / G;
     const int lb = r < g.m ? g.row_ptr[r] : 0, deg = r < g.m ? g.row_ptr[r + 1] - lb : 0;
-    if (__syncthreads_or(deg > kGroupMaxDegree)) {
-      for (int rr = b0 + wave; rr < min(g.m, b0 + R); rr += kWavesPerBlock) {
+    if (__any(deg > kGroupMaxDegree)) {
+      for (int rr = b0 + wave * C::EPW; rr < min(g.m, b0 + (wave + 1) * C::EPW); ++rr) {
         const int lbw = g.row_ptr[rr], degw = g.row_ptr[rr + 1] - lbw;
         Frag<C> qw;
         frag_load<C>(qw, Q + (size_t)rr * hf + hoff, f, gl);
@@ -115,8 +115,8 @@ __global__ __launch_bounds__(kBlock) void gt_rowgroup_bwd_rows_kernel(Csr g, con
   for (int b0 = blockIdx.x * R; b0 < g.m; b0 += gridDim.x * R) {
     const int r = b0 + threadIdx.x / G;
     const int lb = r < g.m ? g.row_ptr[r] : 0, deg = r < g.m ? g.row_ptr[r + 1] - lb : 0;
-    if (__syncthreads_or(deg > kGroupMaxDegree)) {
-      for (int rr = b0 + wave; rr < min(g.m, b0 + R); rr += kWavesPerBlock) {
+    if (__any(deg > kGroupMaxDegree)) {
+      for (int rr = b0 + wave * C::EPW; rr < min(g.m, b0 + (wave + 1) * C::EPW); ++rr) {
         const int lbw = g.row_ptr[rr];
         gt_bwd_row_online<C>(rr, lbw, g.row_ptr[rr + 1] - lbw, g.col_ind, g.val, K + hoff, V + hoff, dO + hoff, P_h, dS_h,
                              hf, f, sw, sc, dQ + hoff, lane);
@@ -160,13 +160,11 @@ __global__ __launch_bounds__(kBlock) void gt_rowgroup_bwd_cols_kernel(
   constexpr int R = kBlock / G;  // rows per block
   const WaveScratch ws = wave_scratch();
   const int lane = ws.lane, wave = ws.wave;
-  float *sw = ws.sw;
-  int *sc = ws.sc;
   for (int b0 = blockIdx.x * R; b0 < g.m; b0 += gridDim.x * R) {
     const int j = b0 + threadIdx.x / G;
     const int lb = j < g.m ? col_ptr[j] : 0, n = j < g.m ? col_ptr[j + 1] - lb : 0;
-    if (__syncthreads_or(n > kGroupMaxDegree)) {
-      for (int jj = b0 + wave; jj < min(g.m, b0 + R); jj += kWavesPerBlock) {
+    if (__any(n > kGroupMaxDegree)) {
+      for (int jj = b0 + wave * C::EPW; jj < min(g.m, b0 + (wave + 1) * C::EPW); ++jj) {
         const int lbw = col_ptr[jj];
         gt_bwd_col_wave<C>(jj, lbw, col_ptr[jj + 1] - lbw, row_ind, val_idx, g.val, Q + hoff, dO + hoff, P_h, dS_h, hf, f,
                            dK + hoff, dV + hoff, lane);
