@@ -13,7 +13,7 @@
 //                     replaces mhspmm_backward_kernel (:609-660) and the atomicAdd into grad_attn_col (:853): the
 //                     column sums are deterministic here.
 // gat_train_wave_kernel runs the wave form over the whole graph or over the ranges a block plan leaves to it;
-// gat_train_group_kernel runs the lane-group form; a wave whose rows include a long one switches to the wave form.
+// gat_train_group_kernel runs the lane-group form; a wave whose rows include a long one puts all its groups on each row.
 //
 // Layouts as in the reference: edge_max / edge_sum / attn_row / attn_col fp32[m, h]; edge_mask fp32[nnz, h]
 // (EDGE-major, CSR order, fused_gatconv_kernel.cu:101).  grad_edge is this library's scratch, fp32[h, nnz].
@@ -224,16 +224,34 @@ __device__ __forceinline__ void gat_bwd_col_wave(const GatTrain &a, int j, int l
 // wave per row wastes most of its lanes.  As in gt_lowdeg.hip: EPW rows per wave, everything in registers, loops to
 // each group's own degree.  The logits are scalars, so the row statistics are exact two-sweep values.
 // ======================================================================================================================
+// Sum / max over the EPW lane groups of a wave (every group ends up with the result).
 template <class C>
-__device__ __forceinline__ void gat_fwd_row_group(const GatTrain &a, int r, int gl) {
+__device__ __forceinline__ float gat_groups_sum(float v) {
+#pragma unroll
+  for (int o = C::G; o < kWave; o <<= 1) v += __shfl_xor(v, o, kWave);
+  return v;
+}
+template <class C>
+__device__ __forceinline__ float gat_groups_max(float v) {
+#pragma unroll
+  for (int o = C::G; o < kWave; o <<= 1) v = fmaxf(v, __shfl_xor(v, o, kWave));
+  return v;
+}
+
+// COOP: the row is taken by all EPW groups of the wave together (group gid: edges gid, gid + EPW, ...), partial
+// results merged across the groups -- for the few long rows of an otherwise low-degree graph.
+template <class C, bool COOP>
+__device__ __forceinline__ void gat_fwd_row_group(const GatTrain &a, int r, int gid, int gl) {
   const int lb = a.row_ptr[r], deg = a.row_ptr[r + 1] - lb;
+  const int e0 = COOP ? gid : 0, es = COOP ? C::EPW : 1;
   const float ar = a.attn_row[a.nh(r)];
   float mx = -INFINITY;
-  for (int e = 0; e < deg; ++e) mx = fmaxf(mx, leaky_relu(ar + a.attn_col[a.nh(a.col_ind[lb + e])], a.slope));
+  for (int e = e0; e < deg; e += es) mx = fmaxf(mx, leaky_relu(ar + a.attn_col[a.nh(a.col_ind[lb + e])], a.slope));
+  if constexpr (COOP) mx = gat_groups_max<C>(mx);
   Frag<C> acc;
   frag_zero<C>(acc);
   float sum = 0.f;
-  for (int e = 0; e < deg; ++e) {
+  for (int e = e0; e < deg; e += es) {
     const int c = a.col_ind[lb + e];
     const float p = fast_exp(leaky_relu(ar + a.attn_col[a.nh(c)], a.slope) - mx);
     sum += p;  // the row sum counts every edge, dropped or not
@@ -241,16 +259,23 @@ __device__ __forceinline__ void gat_fwd_row_group(const GatTrain &a, int r, int 
     frag_load<C>(x, a.Xh + (size_t)c * a.hf, a.f, gl);
     frag_fma<C>(acc, a.keep(lb + e) ? p : 0.f, x);
   }
-  frag_store_scaled<C>(acc, sum != 0.f ? a.dr.scale / sum : 0.f, a.outh + (size_t)r * a.hf, a.f, gl);
-  if (gl == 0) {
-    a.edge_max[a.nh(r)] = deg > 0 ? mx : -1e38f;
-    a.edge_sum[a.nh(r)] = sum;
+  if constexpr (COOP) {
+    sum = gat_groups_sum<C>(sum);
+    frag_reduce_groups<C>(acc);
+  }
+  if (!COOP || gid == 0) {
+    frag_store_scaled<C>(acc, sum != 0.f ? a.dr.scale / sum : 0.f, a.outh + (size_t)r * a.hf, a.f, gl);
+    if (gl == 0) {
+      a.edge_max[a.nh(r)] = deg > 0 ? mx : -1e38f;
+      a.edge_sum[a.nh(r)] = sum;
+    }
   }
 }
 
-template <class C>
-__device__ __forceinline__ void gat_bwd_row_group(const GatTrain &a, int r, int gl) {
+template <class C, bool COOP>
+__device__ __forceinline__ void gat_bwd_row_group(const GatTrain &a, int r, int gid, int gl) {
   const int lb = a.row_ptr[r], deg = a.row_ptr[r + 1] - lb;
+  const int e0 = COOP ? gid : 0, es = COOP ? C::EPW : 1;
   float rs = 0.f;
   if (deg > 0) {
     const float ar = a.attn_row[a.nh(r)];
@@ -258,7 +283,7 @@ __device__ __forceinline__ void gat_bwd_row_group(const GatTrain &a, int r, int 
     Frag<C> go;
     frag_load<C>(go, a.dOh + (size_t)r * a.hf, a.f, gl);
     float t = 0.f;
-    for (int e = 0; e < deg; ++e) {  // g_e parked in grad_edge by lane 0 (every lane of the group holds the same value)
+    for (int e = e0; e < deg; e += es) {  // g_e parked in grad_edge by lane 0 (every lane of the group holds the value)
       const int c = a.col_ind[lb + e];
       Frag<C> x;
       frag_load<C>(x, a.Xh + (size_t)c * a.hf, a.f, gl);
@@ -267,25 +292,27 @@ __device__ __forceinline__ void gat_bwd_row_group(const GatTrain &a, int r, int 
       t = fmaf(fast_exp(leaky_relu(ar + a.attn_col[a.nh(c)], a.slope) - mx) * inv, ge, t);
       if (gl == 0) a.G_h[lb + e] = ge;
     }
-    if (gl == 0)  // lane 0 re-reads what it parked; only it needs the row sum
-      for (int e = 0; e < deg; ++e) {
+    if constexpr (COOP) t = gat_groups_sum<C>(t);
+    if (gl == 0)  // lane 0 of the group re-reads what it parked
+      for (int e = e0; e < deg; e += es) {
         const float pre = ar + a.attn_col[a.nh(a.col_ind[lb + e])];
         const float ge = fast_exp(leaky_relu(pre, a.slope) - mx) * inv * (a.G_h[lb + e] - t) * (pre > 0.f ? 1.f : a.slope);
         a.G_h[lb + e] = ge;
         rs += ge;
       }
   }
-  if (gl == 0) a.grad_row[a.nh(r)] = rs;
+  if constexpr (COOP) rs = gat_groups_sum<C>(rs);  // (lanes gl != 0 hold 0; lane 0 of group 0 gets the total)
+  if (gl == 0 && (!COOP || gid == 0)) a.grad_row[a.nh(r)] = rs;
 }
 
-template <class C>
-__device__ __forceinline__ void gat_bwd_col_group(const GatTrain &a, int j, int gl) {
+template <class C, bool COOP>
+__device__ __forceinline__ void gat_bwd_col_group(const GatTrain &a, int j, int gid, int gl) {
   const int lb = a.col_ptr[j], n = a.col_ptr[j + 1] - lb;
   const float ac = a.attn_col[a.nh(j)];
   Frag<C> acc;
   frag_zero<C>(acc);
   float gs = 0.f;
-  for (int t = 0; t < n; ++t) {
+  for (int t = COOP ? gid : 0; t < n; t += COOP ? C::EPW : 1) {
     const int i = a.row_ind[lb + t], e = a.permute[lb + t];
     const float p = fast_exp(leaky_relu(a.attn_row[a.nh(i)] + ac, a.slope) - a.edge_max[a.nh(i)]) / a.edge_sum[a.nh(i)];
     Frag<C> go;
@@ -293,8 +320,14 @@ __device__ __forceinline__ void gat_bwd_col_group(const GatTrain &a, int j, int 
     frag_fma<C>(acc, a.keep(e) ? p * a.dr.scale : 0.f, go);
     gs += a.G_h[e];
   }
-  frag_store_scaled<C>(acc, 1.f, a.gfeath + (size_t)j * a.hf, a.f, gl);
-  if (gl == 0) a.grad_col[a.nh(j)] = gs;
+  if constexpr (COOP) {
+    frag_reduce_groups<C>(acc);
+    gs = gat_groups_sum<C>(gs);
+  }
+  if (!COOP || gid == 0) {
+    frag_store_scaled<C>(acc, 1.f, a.gfeath + (size_t)j * a.hf, a.f, gl);
+    if (gl == 0) a.grad_col[a.nh(j)] = gs;
+  }
 }
 
 // ======================================================================================================================
@@ -306,11 +339,11 @@ __device__ __forceinline__ void gat_wave_pass(const GatTrain &a, int r, int lane
   else if constexpr (PASS == 1) gat_bwd_row_wave<C>(a, r, lane, sw, sc);
   else gat_bwd_col_wave<C>(a, r, lane, sw, sc);
 }
-template <class C, int PASS>
-__device__ __forceinline__ void gat_group_pass(const GatTrain &a, int r, int gl) {
-  if constexpr (PASS == 0) gat_fwd_row_group<C>(a, r, gl);
-  else if constexpr (PASS == 1) gat_bwd_row_group<C>(a, r, gl);
-  else gat_bwd_col_group<C>(a, r, gl);
+template <class C, int PASS, bool COOP>
+__device__ __forceinline__ void gat_group_pass(const GatTrain &a, int r, int gid, int gl) {
+  if constexpr (PASS == 0) gat_fwd_row_group<C, COOP>(a, r, gid, gl);
+  else if constexpr (PASS == 1) gat_bwd_row_group<C, COOP>(a, r, gid, gl);
+  else gat_bwd_col_group<C, COOP>(a, r, gid, gl);
 }
 
 // general: a wave per row / column over the whole graph (grid-strided) or over the ranges of `rl`
@@ -333,16 +366,13 @@ __global__ __launch_bounds__(kBlock) void gat_train_wave_kernel(GatTrain a, RowL
 
 // low-degree graphs: a workgroup takes blocks of kBlock / G consecutive rows, one lane group per row -- unless a wave's
 // EPW rows include one of more than kGatGroupMaxDegree entries, which a single lane group would walk serially while the
-// rest of the wave waits (a hub of a citation graph): that wave takes its rows one at a time with the wave-per-row
-// routine (a wave-uniform choice: no barrier).
+// rest of the wave waits (a hub of a citation graph): that wave takes its rows one after the other with all its groups
+// on each (COOP).  The choice is wave-uniform (ballot): no barrier, no LDS.
 constexpr int kGatGroupMaxDegree = 24;
 template <class C, int PASS>
 __global__ __launch_bounds__(kBlock) void gat_train_group_kernel(GatTrain a) {
-  __shared__ __attribute__((aligned(16))) float lds[kWavesPerBlock * kScratchFloatsPerWave];
-  constexpr int R = kBlock / C::G;  // rows per block
-  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
-  float *sw = lds + wave * kScratchFloatsPerWave;
-  int *sc = reinterpret_cast<int *>(sw + kWave);
+  constexpr int G = C::G, R = kBlock / G;  // rows per block
+  const int gid = (threadIdx.x & (kWave - 1)) / G, gl = threadIdx.x % G, wave = threadIdx.x / kWave;
   a.head = blockIdx.y;
   a.Xh += (size_t)a.head * a.f;
   a.dOh += (size_t)a.head * a.f;
@@ -351,13 +381,13 @@ __global__ __launch_bounds__(kBlock) void gat_train_group_kernel(GatTrain a) {
   if (a.G_h) a.G_h += (size_t)a.head * a.nnz;
   const int *ptr = PASS == 2 ? a.col_ptr : a.row_ptr;
   for (int b0 = blockIdx.x * R; b0 < a.m; b0 += gridDim.x * R) {
-    const int r = b0 + threadIdx.x / C::G;
+    const int r = b0 + threadIdx.x / G;
     const int deg = r < a.m ? ptr[r + 1] - ptr[r] : 0;
     if (__any(deg > kGatGroupMaxDegree)) {
       for (int rr = b0 + wave * C::EPW; rr < min(a.m, b0 + (wave + 1) * C::EPW); ++rr)
-        gat_wave_pass<C, PASS>(a, rr, lane, sw, sc);
+        gat_group_pass<C, PASS, true>(a, rr, gid, gl);
     } else if (r < a.m) {
-      gat_group_pass<C, PASS>(a, r, threadIdx.x % C::G);
+      gat_group_pass<C, PASS, false>(a, r, gid, gl);
     }
   }
 }
