@@ -222,19 +222,13 @@ __device__ __forceinline__ void gat_bwd_col_wave(const GatTrain &a, int j, int l
 // ======================================================================================================================
 // a group of G lanes (one feature row wide) per row: low-degree graphs (molecules, peptides: ~2 edges per row), where a
 // wave per row wastes most of its lanes.  As in gt_lowdeg.hip: EPW rows per wave, everything in registers, loops to
-// each group's own degree.  The logits are scalars, so the row statistics are exact two-sweep values.
+// each group's own degree.
 // ======================================================================================================================
-// Sum / max over the EPW lane groups of a wave (every group ends up with the result).
+// Sum over the EPW lane groups of a wave (every group ends up with the result).
 template <class C>
 __device__ __forceinline__ float gat_groups_sum(float v) {
 #pragma unroll
   for (int o = C::G; o < kWave; o <<= 1) v += __shfl_xor(v, o, kWave);
-  return v;
-}
-template <class C>
-__device__ __forceinline__ float gat_groups_max(float v) {
-#pragma unroll
-  for (int o = C::G; o < kWave; o <<= 1) v = fmaxf(v, __shfl_xor(v, o, kWave));
   return v;
 }
 
@@ -243,31 +237,44 @@ __device__ __forceinline__ float gat_groups_max(float v) {
 template <class C, bool COOP>
 __device__ __forceinline__ void gat_fwd_row_group(const GatTrain &a, int r, int gid, int gl) {
   const int lb = a.row_ptr[r], deg = a.row_ptr[r + 1] - lb;
-  const int e0 = COOP ? gid : 0, es = COOP ? C::EPW : 1;
   const float ar = a.attn_row[a.nh(r)];
-  float mx = -INFINITY;
-  for (int e = e0; e < deg; e += es) mx = fmaxf(mx, leaky_relu(ar + a.attn_col[a.nh(a.col_ind[lb + e])], a.slope));
-  if constexpr (COOP) mx = gat_groups_max<C>(mx);
   Frag<C> acc;
   frag_zero<C>(acc);
-  float sum = 0.f;
-  for (int e = e0; e < deg; e += es) {
+  float m_run = -INFINITY, l_run = 0.f;  // online softmax: one sweep, one dependent gather chain per edge
+  for (int e = COOP ? gid : 0; e < deg; e += COOP ? C::EPW : 1) {
     const int c = a.col_ind[lb + e];
-    const float p = fast_exp(leaky_relu(ar + a.attn_col[a.nh(c)], a.slope) - mx);
-    sum += p;  // the row sum counts every edge, dropped or not
     Frag<C> x;
     frag_load<C>(x, a.Xh + (size_t)c * a.hf, a.f, gl);
+    const float s = leaky_relu(ar + a.attn_col[a.nh(c)], a.slope);
+    const float m_new = fmaxf(m_run, s);
+    const float sc = (m_run == -INFINITY) ? 0.f : fast_exp(m_run - m_new);
+    const float p = fast_exp(s - m_new);
+    l_run = l_run * sc + p;  // the row sum counts every edge, dropped or not
+    frag_scale<C>(acc, sc);
     frag_fma<C>(acc, a.keep(lb + e) ? p : 0.f, x);
+    m_run = m_new;
   }
-  if constexpr (COOP) {
-    sum = gat_groups_sum<C>(sum);
-    frag_reduce_groups<C>(acc);
+  if constexpr (COOP) {  // merge the groups' (max, sum, accumulator) states pairwise
+#pragma unroll
+    for (int o = C::G; o < kWave; o <<= 1) {
+      const float m_o = __shfl_xor(m_run, o, kWave), l_o = __shfl_xor(l_run, o, kWave);
+      const float m_new = fmaxf(m_run, m_o);
+      const float sa = (m_run == -INFINITY) ? 0.f : fast_exp(m_run - m_new);
+      const float sb = (m_o == -INFINITY) ? 0.f : fast_exp(m_o - m_new);
+      l_run = l_run * sa + l_o * sb;
+#pragma unroll
+      for (int ch = 0; ch < C::NCH; ++ch)
+#pragma unroll
+        for (int k = 0; k < C::VEC; ++k)
+          acc.v[ch][k] = acc.v[ch][k] * sa + __shfl_xor(acc.v[ch][k], o, kWave) * sb;
+      m_run = m_new;
+    }
   }
   if (!COOP || gid == 0) {
-    frag_store_scaled<C>(acc, sum != 0.f ? a.dr.scale / sum : 0.f, a.outh + (size_t)r * a.hf, a.f, gl);
+    frag_store_scaled<C>(acc, l_run != 0.f ? a.dr.scale / l_run : 0.f, a.outh + (size_t)r * a.hf, a.f, gl);
     if (gl == 0) {
-      a.edge_max[a.nh(r)] = deg > 0 ? mx : -1e38f;
-      a.edge_sum[a.nh(r)] = sum;
+      a.edge_max[a.nh(r)] = deg > 0 ? m_run : -1e38f;
+      a.edge_sum[a.nh(r)] = l_run;
     }
   }
 }
