@@ -3,13 +3,13 @@
 'tiling'), C5 (Peptides-like GT multi-head 'hyper' fwd+bwd).  Prints one JSON line per config.
 Timing protocol of the reference: 3 dry + 10 timed calls between device events (DFGNN/utils/util.py:391-400).
 "gattrain": the GAT training pair (general CSR / CSC kernels) on the full-graph configs (cora-like, reddit-like).
-usage: python3 tools/bench_configs.py [c1] [c2] [c4] [c5] [c3gat] [gattrain] [--reddit-scale S]"""
+usage: python3 tests/tools/bench_configs.py [c1] [c2] [c4] [c5] [c3gat] [gattrain] [--reddit-scale S]"""
 import json
 import os
 import sys
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 for p in (ROOT, os.path.join(ROOT, "df-gnn_amd")):
     sys.path.insert(0, p)
 import numpy as np  # noqa: E402

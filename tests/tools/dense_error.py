@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Max abs / relative error of the matrix-core path vs the f64 oracle on a PATTERN-like sample (GT fwd, bwd; GAT)."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 for p in (ROOT, os.path.join(ROOT, "df-gnn_amd")):
     sys.path.insert(0, p)
 import numpy as np, torch

@@ -23,10 +23,3 @@ try:
     print("prep OK")
 except Exception as e:
     print("prep FAIL", e)
-import oracle
-oracle.build()
-try:
-    r = preprocess_Hyper_fw_bw(g)
-    print("prep after oracle import OK")
-except Exception as e:
-    print("prep after oracle FAIL", e)
