@@ -67,18 +67,33 @@ static inline unsigned key_bits(int m) {
 
 static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
+// Keys of up to 18 bits (graphs of up to 262 144 nodes -- every batched workload) are sorted in TWO onesweep passes of
+// 9 bits instead of the three 8-bit passes of rocPRIM's default configuration.
+using Sort9 = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
+                                         rocprim::radix_sort_onesweep_config<
+                                             rocprim::kernel_config<256, 12>, rocprim::kernel_config<256, 16>, 9,
+                                             rocprim::block_radix_rank_algorithm::match>>;
+constexpr unsigned kSort9MaxBits = 18;
+
+template <class KeysIn, class ValsIn>
+static hipError_t sort_pairs(void *temp, size_t &bytes, KeysIn keys_in, int *keys_out, ValsIn vals_in, int *vals_out,
+                             unsigned n, unsigned bits, hipStream_t s) {
+  if (bits <= kSort9MaxBits)
+    return rocprim::radix_sort_pairs<Sort9>(temp, bytes, keys_in, keys_out, vals_in, vals_out, n, 0, bits, s);
+  return rocprim::radix_sort_pairs(temp, bytes, keys_in, keys_out, vals_in, vals_out, n, 0, bits, s);
+}
+
 // rocPRIM temporary storage of the larger of the two sorts
 static int sort_temp_bytes(int m, int nnz, size_t &bytes) {
   bytes = 0;
   size_t a = 0, b = 0;
   const IdNarrow ids{nullptr, 1, m};
   auto keys_a = rocprim::make_transform_iterator(rocprim::counting_iterator<int>(0), ids);
-  if (hipError_t rc = rocprim::radix_sort_pairs(nullptr, a, keys_a, (int *)nullptr, rocprim::counting_iterator<int>(0),
-                                                (int *)nullptr, (unsigned)nnz, 0, key_bits(m), (hipStream_t) nullptr))
+  if (hipError_t rc = sort_pairs(nullptr, a, keys_a, (int *)nullptr, rocprim::counting_iterator<int>(0), (int *)nullptr,
+                                 (unsigned)nnz, key_bits(m), (hipStream_t) nullptr))
     return (int)rc;
-  if (hipError_t rc = rocprim::radix_sort_pairs(nullptr, b, (const int *)nullptr, (int *)nullptr,
-                                                rocprim::counting_iterator<int>(0), (int *)nullptr, (unsigned)nnz, 0,
-                                                key_bits(m), (hipStream_t) nullptr))
+  if (hipError_t rc = sort_pairs(nullptr, b, (const int *)nullptr, (int *)nullptr, rocprim::counting_iterator<int>(0),
+                                 (int *)nullptr, (unsigned)nnz, key_bits(m), (hipStream_t) nullptr))
     return (int)rc;
   bytes = align256(a > b ? a : b);
   return 0;
@@ -125,8 +140,8 @@ int dfgnn_preprocess_hyper(int m, int nnz, const void *src, const void *dst, int
   const IdNarrow srcs{src, idx64, m}, dsts{dst, idx64, m};
   auto row_keys = rocprim::make_transform_iterator(rocprim::counting_iterator<int>(0), srcs);
   size_t tb = temp;
-  if (hipError_t rc = rocprim::radix_sort_pairs(ws, tb, row_keys, rows, rocprim::counting_iterator<int>(0), edge_order,
-                                                (unsigned)nnz, 0, bits, s))
+  if (hipError_t rc = sort_pairs(ws, tb, row_keys, rows, rocprim::counting_iterator<int>(0), edge_order, (unsigned)nnz,
+                                 bits, s))
     return (int)rc;
   csr_pointers_kernel<<<pb, 256, 0, s>>>(m, nnz, rows, row_ptr);
   gather_ids_kernel<<<eb, 256, 0, s>>>(nnz, dsts, edge_order, col_ind);
@@ -135,8 +150,8 @@ int dfgnn_preprocess_hyper(int m, int nnz, const void *src, const void *dst, int
 
   // CSC: (column, CSR slot) sorted by column
   tb = temp;
-  if (hipError_t rc = rocprim::radix_sort_pairs(ws, tb, (const int *)col_ind, sorted_cols,
-                                                rocprim::counting_iterator<int>(0), val_idx, (unsigned)nnz, 0, bits, s))
+  if (hipError_t rc = sort_pairs(ws, tb, (const int *)col_ind, sorted_cols, rocprim::counting_iterator<int>(0), val_idx,
+                                 (unsigned)nnz, bits, s))
     return (int)rc;
   csr_pointers_kernel<<<pb, 256, 0, s>>>(m, nnz, sorted_cols, col_ptr);
   gather_int_kernel<<<eb, 256, 0, s>>>(nnz, rows, val_idx, row_ind);
