@@ -212,7 +212,7 @@ int dfgnn_gat_attn_scores(int m, int h, int f, const float *a_l, const float *a_
 static bool gat_train_dense(Plan &p, const int *rows, const int *plan, const int *plan_meta, int m, int nnz, int f,
                             bool v4) {
   if (!rows || !v4 || !dense_enabled()) return false;
-  if (f != 32 && f != 64 && f != 128) return false;
+  if (f != 16 && f != 32 && f != 64 && f != 128) return false;
   if (!make_plan(p, plan, plan_meta, m, nnz, f)) return false;
   return p.num_dense > 0;
 }

@@ -80,23 +80,27 @@ struct DenseStageRegs {
   static constexpr int PER = (ROWS * (F / 8) + kDenseThreads - 1) / kDenseThreads;  // 8-float pieces per thread
   float4 a[PER], b[PER];
   int row0, row_end;  // the image holds rows [row0, row0 + ROWS) of the matrix; rows at or past row_end are zero
+  int fr;             // real feature count (<= F, a multiple of 8): the image columns at or past it are zero
 };
 
 // rows [row0, row0 + ROWS) of the matrix whose row 0 is `src` (global row stride hf floats); rows at or past row_end
 // (> row0) read as zero.  The loads are unconditional (addresses clamped to the last valid row, the zeroing happens
 // when the image is stored): a load under a branch is waited for right behind the branch, one round trip per piece.
+// fr < F (a narrower matrix run on the F-wide kernels, e.g. f = 16 heads on the 32-wide instance): the pieces past fr are
+// read from the row's first piece instead (a valid address) and zeroed with the padding rows.
 template <int F, int ROWS>
 __device__ __forceinline__ void dense_stage_load(DenseStageRegs<F, ROWS> &r, const float *__restrict__ src, size_t hf,
-                                                 int row0, int row_end) {
+                                                 int row0, int row_end, int fr = F) {
   constexpr int C8 = F / 8;
   const int tid = opaque_tid();
   r.row0 = row0;
   r.row_end = row_end;
+  r.fr = fr;
 #pragma unroll
   for (int k = 0; k < DenseStageRegs<F, ROWS>::PER; ++k) {
     const int idx = tid + k * kDenseThreads;
     const int row = min(idx / C8, ROWS - 1), c8 = idx % C8;
-    const unsigned off = (unsigned)min(row0 + row, row_end - 1) * (unsigned)hf + 8u * c8;  // < 2^31: < 256 rows
+    const unsigned off = (unsigned)min(row0 + row, row_end - 1) * (unsigned)hf + (8 * c8 < fr ? 8u * c8 : 0u);  // < 2^31
     r.a[k] = ld32_f4(src, off);
     r.b[k] = ld32_f4(src, off + 4);
   }
@@ -115,7 +119,7 @@ __device__ __forceinline__ void dense_stage_store(DenseStageRegs<F, ROWS> &r, __
     const int idx = tid + k * kDenseThreads;
     const int row = idx / C8, c8 = idx - row * C8;
     if (idx < ROWS * C8) {
-      const bool valid = r.row0 + row < r.row_end;
+      const bool valid = r.row0 + row < r.row_end && 8 * c8 < r.fr;
       const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
       bf16x8 h, l;
       split_bf16x8(valid ? r.a[k] : z, valid ? r.b[k] : z, h, l);
@@ -247,12 +251,15 @@ __device__ __forceinline__ void dense_cols_mma(f32x4 (&acc)[F / 16], const __bf1
   dense_kblock_mma<F, GMAX>(acc, ihi, ilo, (32 * jb + 4 * L.mq + L.tq) * RS + 4 * L.tp, 16 * RS, yh, yl);
 }
 
-// accumulator tiles -> a global row: lane (mi, mq), register r of tile ft = feature 16 ft + 4 mq + r
+// accumulator tiles -> a global row: lane (mi, mq), register r of tile ft = feature 16 ft + 4 mq + r.
+// feat0 = the feature of this lane's first value (4 mq, plus the tile offset of a single-tile call), fr = the real
+// feature count: nothing is stored (or read back) at or past it.
 template <int NFT>
 __device__ __forceinline__ void dense_store_acc(const f32x4 (&acc)[NFT], float scale, float *__restrict__ base,
-                                                unsigned off, bool accumulate) {
+                                                unsigned off, bool accumulate, int feat0 = 0, int fr = 1 << 30) {
 #pragma unroll
   for (int ft = 0; ft < NFT; ++ft) {
+    if (feat0 + 16 * ft >= fr) continue;
     float4 o = make_float4(acc[ft][0] * scale, acc[ft][1] * scale, acc[ft][2] * scale, acc[ft][3] * scale);
     if (accumulate) {
       const float4 old = ld32_f4(base, off + 16 * ft);

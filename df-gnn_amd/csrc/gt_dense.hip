@@ -73,7 +73,8 @@ __device__ __forceinline__ void dense_fwd_body(float *lds, int lds_bytes, const 
   float *pstage = acl + (GAT ? npad : 0);                          // [ne] normalised attention values, if it fits
   const size_t fixed_bytes = (size_t)(reinterpret_cast<char *>(pstage) - reinterpret_cast<char *>(lds));
   const bool stage_attn = WRITE_ATTN && fixed_bytes + (size_t)ne * 4 <= (size_t)lds_bytes;
-  const size_t hf = (size_t)g.h * F, hoff = (size_t)head * F;
+  const int fr = g.f;  // real feature width (== F, or narrower: f = 16 runs on the 32-wide instance, zero-padded)
+  const size_t hf = (size_t)g.h * fr, hoff = (size_t)head * fr;
   const float *Qb = Q + (size_t)n0 * hf + hoff, *Kb = K + (size_t)n0 * hf + hoff, *Vb = V + (size_t)n0 * hf + hoff;
   float *Ob = out + (size_t)n0 * hf + hoff;
   (void)Qb;
@@ -106,7 +107,7 @@ __device__ __forceinline__ void dense_fwd_body(float *lds, int lds_bytes, const 
     }
   }
   DenseStageRegs<F, CR> st;
-  dense_stage_load<F, CR>(st, GAT ? Vb : Kb, hf, 0, n);  // the first image: K rows (GAT: X rows)
+  dense_stage_load<F, CR>(st, GAT ? Vb : Kb, hf, 0, n, fr);  // the first image: K rows (GAT: X rows)
   float4 qa[NS][KT], qb[NS][KT];  // this lane's pieces of its strips' Q rows, raw: converted after the map is built
   float ar[NS];
 #pragma unroll
@@ -116,11 +117,12 @@ __device__ __forceinline__ void dense_fwd_body(float *lds, int lds_bytes, const 
     if constexpr (GAT) {
       ar[s] = Q[(size_t)(n0 + i) * g.h + head];
     } else {
-      const unsigned off = (unsigned)i * (unsigned)hf + 8u * L.mq;
+      const unsigned off = (unsigned)i * (unsigned)hf;
 #pragma unroll
       for (int t = 0; t < KT; ++t) {
-        qa[s][t] = ld32_f4(Qb, off + 32 * t);
-        qb[s][t] = ld32_f4(Qb, off + 32 * t + 4);
+        const unsigned c = (32 * t + 8 * L.mq < fr) ? 32u * t + 8u * L.mq : 0u;  // (past fr: a valid address, zeroed below)
+        qa[s][t] = ld32_f4(Qb, off + c);
+        qb[s][t] = ld32_f4(Qb, off + c + 4);
       }
     }
   }
@@ -161,7 +163,7 @@ __device__ __forceinline__ void dense_fwd_body(float *lds, int lds_bytes, const 
 #pragma unroll
       for (int t = 0; t < KT; ++t) {
         float4 a = qa[s][t], b = qb[s][t];
-        if (!valid) a = b = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (!valid || 32 * t + 8 * L.mq >= fr) a = b = make_float4(0.f, 0.f, 0.f, 0.f);
         split_bf16x8(a, b, qh[s][t], ql[s][t]);
       }
     }
@@ -170,10 +172,10 @@ __device__ __forceinline__ void dense_fwd_body(float *lds, int lds_bytes, const 
   DFGNN_DSTAMP(1)
   // the next image (the second K chunk of a two-chunk range, else V rows 0..) lands during the S phase
   if constexpr (GAT) {
-    if (NCH > 1) dense_stage_load<F, CR>(st, Vb, hf, CR, n);
+    if (NCH > 1) dense_stage_load<F, CR>(st, Vb, hf, CR, n, fr);
   } else {
-    if (NCH == 1) dense_stage_load<F, CR>(st, Vb, hf, 0, n);
-    else dense_stage_load<F, CR>(st, Kb, hf, CR, n);
+    if (NCH == 1) dense_stage_load<F, CR>(st, Vb, hf, 0, n, fr);
+    else dense_stage_load<F, CR>(st, Kb, hf, CR, n, fr);
   }
 
   // ---- S^T = K Q^T (GAT: the rank-one logits) ------------------------------------------------------------------------
@@ -194,7 +196,7 @@ __device__ __forceinline__ void dense_fwd_body(float *lds, int lds_bytes, const 
     if (c > 0) {
       lds_barrier();
       dense_stage_store<F, CR>(st, ihi, ilo);
-      dense_stage_load<F, CR>(st, Vb, hf, 0, n);  // V rows 0.., for the first O^T chunk
+      dense_stage_load<F, CR>(st, Vb, hf, 0, n, fr);  // V rows 0.., for the first O^T chunk
       lds_barrier();
     }
     const LaneIds L = lane_ids();
@@ -309,7 +311,7 @@ __device__ __forceinline__ void dense_fwd_body(float *lds, int lds_bytes, const 
     if (!(GAT && c == 0)) {  // (GAT: X rows 0.. are the image already)
       lds_barrier();       // every strip is done with the previous image
       dense_stage_store<F, CR>(st, ihi, ilo);
-      if (c + 1 < NCH) dense_stage_load<F, CR>(st, Vb, hf, (c + 1) * CR, n);
+      if (c + 1 < NCH) dense_stage_load<F, CR>(st, Vb, hf, (c + 1) * CR, n, fr);
       lds_barrier();
     }
     if (c == 0) { DFGNN_DSTAMP(4) }
@@ -329,7 +331,7 @@ __device__ __forceinline__ void dense_fwd_body(float *lds, int lds_bytes, const 
   for (int s = 0; s < NS; ++s) {
     const LaneIds L = lane_ids();
     const int i = (wave + 8 * s) * 16 + L.mi;
-    if (i < n) dense_store_acc<FT>(o[s], inv[s], Ob, (unsigned)i * (unsigned)hf + 4u * L.mq, false);
+    if (i < n) dense_store_acc<FT>(o[s], inv[s], Ob, (unsigned)i * (unsigned)hf + 4u * L.mq, false, 4 * L.mq, fr);
   }
   DFGNN_DSTAMP(5)
   DFGNN_DSTAMP(6)
@@ -426,7 +428,8 @@ __device__ __forceinline__ void dense_bwd_body(float *lds, const Csr &g, int n0,
   __bf16 *ihi = reinterpret_cast<__bf16 *>(lds), *ilo = ihi + (size_t)CW * RS;
   float *T = reinterpret_cast<float *>(ilo + (size_t)CW * RS);
   __bf16 *Tb = reinterpret_cast<__bf16 *>(T);
-  const size_t hf = (size_t)g.h * F, hoff = (size_t)head * F;
+  const int fr = g.f;  // real feature width (see the forward)
+  const size_t hf = (size_t)g.h * fr, hoff = (size_t)head * fr;
   const float *Qb = Q + (size_t)n0 * hf + hoff, *Kb = K + (size_t)n0 * hf + hoff, *Vb = V + (size_t)n0 * hf + hoff,
               *dOb = dO + (size_t)n0 * hf + hoff;
   float *dQb = dQ + (size_t)n0 * hf + hoff, *dKb = dK + (size_t)n0 * hf + hoff, *dVb = dV + (size_t)n0 * hf + hoff;
@@ -460,11 +463,11 @@ __device__ __forceinline__ void dense_bwd_body(float *lds, const Csr &g, int n0,
       next_row0 = row0;
       next_end = row_end;
     } else {
-      dense_stage_load<F, CW>(st, src, hf, row0, row_end);
+      dense_stage_load<F, CW>(st, src, hf, row0, row_end, fr);
     }
   };
   auto image_commit = [&]() {
-    if (NBLK > 1) dense_stage_load<F, CW>(st, next_src, hf, next_row0, next_end);
+    if (NBLK > 1) dense_stage_load<F, CW>(st, next_src, hf, next_row0, next_end, fr);
     dense_stage_store<F, CW>(st, ihi, ilo);
   };
   // Edges of a row block (CSR order, contiguous) are fetched several per thread at a time -- loads first, then the
@@ -565,7 +568,7 @@ __device__ __forceinline__ void dense_bwd_body(float *lds, const Csr &g, int n0,
         dense_kblock_mma<F, (NBLK == 1 ? 8 : 4)>(acc, ihi, ilo, (32 * ib + 4 * L.mq + L.tq) * RS + 4 * L.tp, 16 * RS, yh, yl);
       }
     }
-    if (j < n) dense_store_acc<FT>(acc, 1.f, outb, (unsigned)j * (unsigned)hf + 4u * L.mq, accumulate);
+    if (j < n) dense_store_acc<FT>(acc, 1.f, outb, (unsigned)j * (unsigned)hf + 4u * L.mq, accumulate, 4 * L.mq, fr);
   };
   // one 16 x 16 output tile (column strip cs, feature tile ft): the unit of work for the strips past the eighth,
   // which are dealt out tile by tile so that all waves share them
@@ -587,7 +590,8 @@ __device__ __forceinline__ void dense_bwd_body(float *lds, const Csr &g, int n0,
         acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, yl, acc[0], 0, 0, 0);
       }
     }
-    if (j < n) dense_store_acc<1>(acc, 1.f, outb, (unsigned)j * (unsigned)hf + 16u * ft + 4u * L.mq, accumulate);
+    if (j < n)
+      dense_store_acc<1>(acc, 1.f, outb, (unsigned)j * (unsigned)hf + 16u * ft + 4u * L.mq, accumulate, 16 * ft + 4 * L.mq, fr);
   };
   auto column_phase = [&](float *outb, int j0, int ni, bool accumulate) {
     const int nstrips = min(U, (n - j0 + 15) >> 4);
@@ -791,7 +795,7 @@ __device__ __forceinline__ void dense_bwd_body(float *lds, const Csr &g, int n0,
         }
         if (jc + 1 == NBLK) {  // dQ rows of this row block are complete: store them now, under the dK product
           const int i = i0 + wave * 16 + L.mi;
-          if (i < i0 + ni) dense_store_acc<FT>(qacc, 1.f, dQb, (unsigned)i * (unsigned)hf + 4u * L.mq, false);
+          if (i < i0 + ni) dense_store_acc<FT>(qacc, 1.f, dQb, (unsigned)i * (unsigned)hf + 4u * L.mq, false, 4 * L.mq, fr);
         }
       }
       DFGNN_DSTAMP(6)
@@ -868,6 +872,7 @@ bool dense_enabled() {
 
 template <class Fn>
 static int dispatch_dense(int f, Fn &&fn) {
+  if (f == 16) return fn(std::integral_constant<int, 32>{});  // zero-padded to the narrowest instance (g.f stays 16)
   if (f == 32) return fn(std::integral_constant<int, 32>{});
   if (f == 64) return fn(std::integral_constant<int, 64>{});
   if (f == 128) return fn(std::integral_constant<int, 128>{});

@@ -338,11 +338,14 @@ def test_block_plan_structure():
     assert set(np.cumsum(sizes)).issuperset(set(fit[:, 1]))                              # = graph boundaries
     assert maxn == (fit[:, 1] - fit[:, 0]).max() and maxn <= 256
     assert maxe == (rp[fit[:, 1]] - rp[fit[:, 0]]).max()
-    # f = 16: many graphs merge into one block of <= 256 nodes
+    # f = 8: no matrix-core form; many graphs merge into one block of <= 256 nodes
+    plan8 = build_plan(row_ptr, col_ind, 8)
+    fit8 = plan8.buf.cpu().numpy()[12:12 + 2 * plan8.meta[0]].reshape(-1, 2) & ~FLAGS
+    assert plan8.num_dense == 0
+    assert plan8.meta[0] < nfit and (fit8[:, 1] - fit8[:, 0]).max() <= 256
+    # f = 16 runs zero-padded on the 32-wide matrix-core instance: same classification as f = 128
     plan16 = build_plan(row_ptr, col_ind, 16)
-    fit16 = plan16.buf.cpu().numpy()[12:12 + 2 * plan16.meta[0]].reshape(-1, 2) & ~FLAGS
-    assert plan16.num_dense == 0                                                         # f = 16 has no matrix-core form
-    assert plan16.meta[0] < nfit and (fit16[:, 1] - fit16[:, 0]).max() <= 256
+    assert plan16.num_dense == nd and plan16.meta[0] == nfit
     # a full graph is one closed range that cannot fit: everything spills in <= 16-row chunks
     c = S.cora_like()
     rp2, ci2, _, _, _ = preprocess_Hyper(c.to(DEV))
@@ -411,7 +414,7 @@ def test_block_kernels_match_oracle_and_general_path(oracle_mod, h, f, bs, unit_
     assert torch.allclose(out_b, out_n, atol=1e-5, rtol=1e-4)
 
 
-@pytest.mark.parametrize("h,f", [(1, 128), (2, 64), (3, 32)])
+@pytest.mark.parametrize("h,f", [(1, 128), (2, 64), (3, 32), (4, 16)])
 def test_dense_kernels_every_geometry(oracle_mod, h, f):
     """Matrix-core kernels (gt_dense.hip) vs the oracle on a batch whose ranges hit every code path: tiny graphs
     (1 strip), <= 128 nodes (one tile), 129-160 nodes (160-row images, two row blocks), 161-255 nodes (2 x 2 tiles),
@@ -619,7 +622,7 @@ def test_gat_train_pattern_like_batch(oracle_mod):
 
 
 @pytest.mark.parametrize("attn_drop", [0.0, 0.4])
-@pytest.mark.parametrize("h,f", [(1, 128), (2, 64), (3, 32)])
+@pytest.mark.parametrize("h,f", [(1, 128), (2, 64), (3, 32), (4, 16)])
 def test_gat_train_dense_every_geometry(oracle_mod, h, f, attn_drop):
     """GAT training pair on the matrix-core kernels (gat_dense_fwd_kernel with row statistics, gat_dense_bwd_kernel): a
     batch whose ranges are all dense and hit every geometry (1 strip, <= 128 nodes, 129-160 nodes with two row blocks,
@@ -895,7 +898,7 @@ def _reference_plan(row_ptr, col_ind, f, budget, merge_nodes):
         dup[i + 1] = dup[i] + bad
     lite = lambda n, e: min(n, 1 << 16) * (4 * f + 8) + min(e, 1 << 24) * (1 if min(n, 1 << 16) <= 256 else 2)  # noqa: E731
     full = lambda n, e: lite(n, e) + 4 * min(e, 1 << 24)  # noqa: E731
-    dense_f = f in (32, 64, 128)
+    dense_f = f in (16, 32, 64, 128)
     fit, spill = [], []
 
     def flush(n0, n1):
