@@ -52,7 +52,9 @@ struct DenseDrop {
   float drop = 0.f, scale = 1.f;
 };
 
-template <int F, bool WRITE_ATTN, int NS, int CR, int NCH, bool GAT = false>
+// FR: the real feature width.  Widths below the narrowest MFMA k-step (f = 16: the heads of multi-head GT configs) run
+// zero-padded on the 32-wide layout (F below); for FR >= 32 every padding guard folds away at compile time.
+template <int FR, bool WRITE_ATTN, int NS, int CR, int NCH, bool GAT = false>
 __device__ __forceinline__ void dense_fwd_body(float *lds, int lds_bytes, const Csr &g, int n0, int n, int e0, int ne,
                                                int head, const float *__restrict__ Q, const float *__restrict__ K,
                                                const float *__restrict__ V, float *__restrict__ attn_edge,
@@ -60,6 +62,8 @@ __device__ __forceinline__ void dense_fwd_body(float *lds, int lds_bytes, const 
                                                float *__restrict__ stat_max = nullptr,
                                                float *__restrict__ stat_sum = nullptr,
                                                const DenseDrop drop = DenseDrop{}) {
+  constexpr int F = FR < 32 ? 32 : FR;  // layout width
+  constexpr int fr = FR;
   using D = DenseCfg<F>;
   constexpr int RS = D::RS, KT = D::KT, FT = D::FT, TPC = CR / 16, NT = TPC * NCH;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
@@ -73,7 +77,6 @@ __device__ __forceinline__ void dense_fwd_body(float *lds, int lds_bytes, const 
   float *pstage = acl + (GAT ? npad : 0);                          // [ne] normalised attention values, if it fits
   const size_t fixed_bytes = (size_t)(reinterpret_cast<char *>(pstage) - reinterpret_cast<char *>(lds));
   const bool stage_attn = WRITE_ATTN && fixed_bytes + (size_t)ne * 4 <= (size_t)lds_bytes;
-  const int fr = g.f;  // real feature width (== F, or narrower: f = 16 runs on the 32-wide instance, zero-padded)
   const size_t hf = (size_t)g.h * fr, hoff = (size_t)head * fr;
   const float *Qb = Q + (size_t)n0 * hf + hoff, *Kb = K + (size_t)n0 * hf + hoff, *Vb = V + (size_t)n0 * hf + hoff;
   float *Ob = out + (size_t)n0 * hf + hoff;
@@ -411,13 +414,15 @@ struct GatBwdArgs {
   DenseDrop drop;                    // attention dropout: a dropped edge enters the P tile with a negative sign
 };
 
-template <int F, int CW, int NBLK, bool GAT = false>
+template <int FR, int CW, int NBLK, bool GAT = false>
 __device__ __forceinline__ void dense_bwd_body(float *lds, const Csr &g, int n0, int n, int e0, int ne, int head,
                                                const float *__restrict__ Q, const float *__restrict__ K,
                                                const float *__restrict__ V, const float *__restrict__ attn_edge,
                                                const float *__restrict__ dO, float *__restrict__ dQ,
                                                float *__restrict__ dK, float *__restrict__ dV,
                                                const GatBwdArgs ga = GatBwdArgs{}) {
+  constexpr int F = FR < 32 ? 32 : FR;  // layout width (see dense_fwd_body)
+  constexpr int fr = FR;
   using D = DenseCfg<F>;
   using G = DenseBwdGeom<CW, NBLK>;
   constexpr int RS = D::RS, KT = D::KT, FT = D::FT, RB = G::RB, RBP = G::RBP, U = G::U, TS = G::TS;
@@ -428,7 +433,6 @@ __device__ __forceinline__ void dense_bwd_body(float *lds, const Csr &g, int n0,
   __bf16 *ihi = reinterpret_cast<__bf16 *>(lds), *ilo = ihi + (size_t)CW * RS;
   float *T = reinterpret_cast<float *>(ilo + (size_t)CW * RS);
   __bf16 *Tb = reinterpret_cast<__bf16 *>(T);
-  const int fr = g.f;  // real feature width (see the forward)
   const size_t hf = (size_t)g.h * fr, hoff = (size_t)head * fr;
   const float *Qb = Q + (size_t)n0 * hf + hoff, *Kb = K + (size_t)n0 * hf + hoff, *Vb = V + (size_t)n0 * hf + hoff,
               *dOb = dO + (size_t)n0 * hf + hoff;
@@ -872,7 +876,7 @@ bool dense_enabled() {
 
 template <class Fn>
 static int dispatch_dense(int f, Fn &&fn) {
-  if (f == 16) return fn(std::integral_constant<int, 32>{});  // zero-padded to the narrowest instance (g.f stays 16)
+  if (f == 16) return fn(std::integral_constant<int, 16>{});  // zero-padded onto the 32-wide layout
   if (f == 32) return fn(std::integral_constant<int, 32>{});
   if (f == 64) return fn(std::integral_constant<int, 64>{});
   if (f == 128) return fn(std::integral_constant<int, 128>{});
