@@ -80,7 +80,6 @@ struct DenseStageRegs {
   static constexpr int PER = (ROWS * (F / 8) + kDenseThreads - 1) / kDenseThreads;  // 8-float pieces per thread
   float4 a[PER], b[PER];
   int row0, row_end;  // the image holds rows [row0, row0 + ROWS) of the matrix; rows at or past row_end are zero
-  int fr;             // real feature count (<= F, a multiple of 8): the image columns at or past it are zero
 };
 
 // rows [row0, row0 + ROWS) of the matrix whose row 0 is `src` (global row stride hf floats); rows at or past row_end
@@ -95,7 +94,6 @@ __device__ __forceinline__ void dense_stage_load(DenseStageRegs<F, ROWS> &r, con
   const int tid = opaque_tid();
   r.row0 = row0;
   r.row_end = row_end;
-  r.fr = fr;
 #pragma unroll
   for (int k = 0; k < DenseStageRegs<F, ROWS>::PER; ++k) {
     const int idx = tid + k * kDenseThreads;
@@ -110,8 +108,9 @@ __device__ __forceinline__ void dense_stage_load(DenseStageRegs<F, ROWS> &r, con
 // interleaved with the stores piece by piece: memory returns in order, so each piece would then wait for the loads
 // that were just issued.  (Pinning the bf16 conversion here with an empty asm, so that the scheduler cannot hoist it
 // and the wait for the data to the previous barrier, measured 2 % slower.)
+// fr: real feature count (<= F, a multiple of 8): the image columns at or past it are stored as zeros.
 template <int F, int ROWS>
-__device__ __forceinline__ void dense_stage_store(DenseStageRegs<F, ROWS> &r, __bf16 *hi, __bf16 *lo) {
+__device__ __forceinline__ void dense_stage_store(DenseStageRegs<F, ROWS> &r, __bf16 *hi, __bf16 *lo, int fr = F) {
   constexpr int C8 = F / 8, RS = DenseCfg<F>::RS;
   const int tid = opaque_tid();
 #pragma unroll
@@ -119,7 +118,7 @@ __device__ __forceinline__ void dense_stage_store(DenseStageRegs<F, ROWS> &r, __
     const int idx = tid + k * kDenseThreads;
     const int row = idx / C8, c8 = idx - row * C8;
     if (idx < ROWS * C8) {
-      const bool valid = r.row0 + row < r.row_end && 8 * c8 < r.fr;
+      const bool valid = r.row0 + row < r.row_end && 8 * c8 < fr;
       const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
       bf16x8 h, l;
       split_bf16x8(valid ? r.a[k] : z, valid ? r.b[k] : z, h, l);

@@ -156,7 +156,7 @@ __device__ __forceinline__ void dense_fwd_body(float *lds, int lds_bytes, const 
       else map[i * MS + j] = (unsigned char)(e - rp[i]);
     }
   }
-  dense_stage_store<F, CR>(st, ihi, ilo);
+  dense_stage_store<F, CR>(st, ihi, ilo, fr);
   bf16x8 qh[NS][KT], ql[NS][KT];
   if constexpr (!GAT) {
 #pragma unroll
@@ -198,7 +198,7 @@ __device__ __forceinline__ void dense_fwd_body(float *lds, int lds_bytes, const 
   for (int c = 0; c < (GAT ? 0 : NCH); ++c) {
     if (c > 0) {
       lds_barrier();
-      dense_stage_store<F, CR>(st, ihi, ilo);
+      dense_stage_store<F, CR>(st, ihi, ilo, fr);
       dense_stage_load<F, CR>(st, Vb, hf, 0, n, fr);  // V rows 0.., for the first O^T chunk
       lds_barrier();
     }
@@ -313,7 +313,7 @@ __device__ __forceinline__ void dense_fwd_body(float *lds, int lds_bytes, const 
   for (int c = 0; c < NCH; ++c) {
     if (!(GAT && c == 0)) {  // (GAT: X rows 0.. are the image already)
       lds_barrier();       // every strip is done with the previous image
-      dense_stage_store<F, CR>(st, ihi, ilo);
+      dense_stage_store<F, CR>(st, ihi, ilo, fr);
       if (c + 1 < NCH) dense_stage_load<F, CR>(st, Vb, hf, (c + 1) * CR, n, fr);
       lds_barrier();
     }
@@ -472,7 +472,7 @@ __device__ __forceinline__ void dense_bwd_body(float *lds, const Csr &g, int n0,
   };
   auto image_commit = [&]() {
     if (NBLK > 1) dense_stage_load<F, CW>(st, next_src, hf, next_row0, next_end, fr);
-    dense_stage_store<F, CW>(st, ihi, ilo);
+    dense_stage_store<F, CW>(st, ihi, ilo, fr);
   };
   // Edges of a row block (CSR order, contiguous) are fetched several per thread at a time -- loads first, then the
   // scatter into the fp32 tile -- so that a batch costs one memory round trip; the first batch of a range is
