@@ -98,7 +98,7 @@ __device__ __forceinline__ void dense_stage_load(DenseStageRegs<F, ROWS> &r, con
   for (int k = 0; k < DenseStageRegs<F, ROWS>::PER; ++k) {
     const int idx = tid + k * kDenseThreads;
     const int row = min(idx / C8, ROWS - 1), c8 = idx % C8;
-    const unsigned off = (unsigned)min(row0 + row, row_end - 1) * (unsigned)hf + (8 * c8 < fr ? 8u * c8 : 0u);  // < 2^31
+    const unsigned off = (unsigned)min(row0 + row, row_end - 1) * (unsigned)hf + ((fr >= F || 8 * c8 < fr) ? 8u * c8 : 0u);
     r.a[k] = ld32_f4(src, off);
     r.b[k] = ld32_f4(src, off + 4);
   }
@@ -118,7 +118,7 @@ __device__ __forceinline__ void dense_stage_store(DenseStageRegs<F, ROWS> &r, __
     const int idx = tid + k * kDenseThreads;
     const int row = idx / C8, c8 = idx - row * C8;
     if (idx < ROWS * C8) {
-      const bool valid = r.row0 + row < r.row_end && 8 * c8 < fr;
+      const bool valid = r.row0 + row < r.row_end && (fr >= F || 8 * c8 < fr);
       const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
       bf16x8 h, l;
       split_bf16x8(valid ? r.a[k] : z, valid ? r.b[k] : z, h, l);
@@ -251,14 +251,16 @@ __device__ __forceinline__ void dense_cols_mma(f32x4 (&acc)[F / 16], const __bf1
 }
 
 // accumulator tiles -> a global row: lane (mi, mq), register r of tile ft = feature 16 ft + 4 mq + r.
-// feat0 = the feature of this lane's first value (4 mq, plus the tile offset of a single-tile call), fr = the real
-// feature count: nothing is stored (or read back) at or past it.
-template <int NFT>
+// GUARD (padded widths only): feat0 = the feature of this lane's first value (4 mq, plus the tile offset of a
+// single-tile call), fr = the real feature count: nothing is stored (or read back) at or past it.  Unguarded, the
+// stores and the read-backs stay free of branches (a load under a branch is waited for right behind it).
+template <int NFT, bool GUARD = false>
 __device__ __forceinline__ void dense_store_acc(const f32x4 (&acc)[NFT], float scale, float *__restrict__ base,
                                                 unsigned off, bool accumulate, int feat0 = 0, int fr = 1 << 30) {
 #pragma unroll
   for (int ft = 0; ft < NFT; ++ft) {
-    if (feat0 + 16 * ft >= fr) continue;
+    if constexpr (GUARD)
+      if (feat0 + 16 * ft >= fr) continue;
     float4 o = make_float4(acc[ft][0] * scale, acc[ft][1] * scale, acc[ft][2] * scale, acc[ft][3] * scale);
     if (accumulate) {
       const float4 old = ld32_f4(base, off + 16 * ft);

@@ -123,7 +123,7 @@ __device__ __forceinline__ void dense_fwd_body(float *lds, int lds_bytes, const 
       const unsigned off = (unsigned)i * (unsigned)hf;
 #pragma unroll
       for (int t = 0; t < KT; ++t) {
-        const unsigned c = (32 * t + 8 * L.mq < fr) ? 32u * t + 8u * L.mq : 0u;  // (past fr: a valid address, zeroed below)
+        const unsigned c = (FR == F || 32 * t + 8 * L.mq < fr) ? 32u * t + 8u * L.mq : 0u;  // (past fr: zeroed below)
         qa[s][t] = ld32_f4(Qb, off + c);
         qb[s][t] = ld32_f4(Qb, off + c + 4);
       }
@@ -166,7 +166,7 @@ __device__ __forceinline__ void dense_fwd_body(float *lds, int lds_bytes, const 
 #pragma unroll
       for (int t = 0; t < KT; ++t) {
         float4 a = qa[s][t], b = qb[s][t];
-        if (!valid || 32 * t + 8 * L.mq >= fr) a = b = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (!valid || (FR < F && 32 * t + 8 * L.mq >= fr)) a = b = make_float4(0.f, 0.f, 0.f, 0.f);
         split_bf16x8(a, b, qh[s][t], ql[s][t]);
       }
     }
@@ -334,7 +334,7 @@ __device__ __forceinline__ void dense_fwd_body(float *lds, int lds_bytes, const 
   for (int s = 0; s < NS; ++s) {
     const LaneIds L = lane_ids();
     const int i = (wave + 8 * s) * 16 + L.mi;
-    if (i < n) dense_store_acc<FT>(o[s], inv[s], Ob, (unsigned)i * (unsigned)hf + 4u * L.mq, false, 4 * L.mq, fr);
+    if (i < n) dense_store_acc<FT, (FR < F)>(o[s], inv[s], Ob, (unsigned)i * (unsigned)hf + 4u * L.mq, false, 4 * L.mq, fr);
   }
   DFGNN_DSTAMP(5)
   DFGNN_DSTAMP(6)
@@ -572,7 +572,7 @@ __device__ __forceinline__ void dense_bwd_body(float *lds, const Csr &g, int n0,
         dense_kblock_mma<F, (NBLK == 1 ? 8 : 4)>(acc, ihi, ilo, (32 * ib + 4 * L.mq + L.tq) * RS + 4 * L.tp, 16 * RS, yh, yl);
       }
     }
-    if (j < n) dense_store_acc<FT>(acc, 1.f, outb, (unsigned)j * (unsigned)hf + 4u * L.mq, accumulate, 4 * L.mq, fr);
+    if (j < n) dense_store_acc<FT, (FR < F)>(acc, 1.f, outb, (unsigned)j * (unsigned)hf + 4u * L.mq, accumulate, 4 * L.mq, fr);
   };
   // one 16 x 16 output tile (column strip cs, feature tile ft): the unit of work for the strips past the eighth,
   // which are dealt out tile by tile so that all waves share them
@@ -595,7 +595,7 @@ __device__ __forceinline__ void dense_bwd_body(float *lds, const Csr &g, int n0,
       }
     }
     if (j < n)
-      dense_store_acc<1>(acc, 1.f, outb, (unsigned)j * (unsigned)hf + 16u * ft + 4u * L.mq, accumulate, 16 * ft + 4 * L.mq, fr);
+      dense_store_acc<1, (FR < F)>(acc, 1.f, outb, (unsigned)j * (unsigned)hf + 16u * ft + 4u * L.mq, accumulate, 16 * ft + 4 * L.mq, fr);
   };
   auto column_phase = [&](float *outb, int j0, int ni, bool accumulate) {
     const int nstrips = min(U, (n - j0 + 15) >> 4);
@@ -799,7 +799,7 @@ __device__ __forceinline__ void dense_bwd_body(float *lds, const Csr &g, int n0,
         }
         if (jc + 1 == NBLK) {  // dQ rows of this row block are complete: store them now, under the dK product
           const int i = i0 + wave * 16 + L.mi;
-          if (i < i0 + ni) dense_store_acc<FT>(qacc, 1.f, dQb, (unsigned)i * (unsigned)hf + 4u * L.mq, false, 4 * L.mq, fr);
+          if (i < i0 + ni) dense_store_acc<FT, (FR < F)>(qacc, 1.f, dQb, (unsigned)i * (unsigned)hf + 4u * L.mq, false, 4 * L.mq, fr);
         }
       }
       DFGNN_DSTAMP(6)
