@@ -23,6 +23,13 @@ inline bool make_plan(Plan &p, const int *plan_dev, const int *meta, int m, int 
   return true;
 }
 
+// A built plan is usable for width f when the LDS-resident kernels have an exact lane layout for f, or -- f = 8, which
+// has none -- when every fit range goes to the matrix-core kernels anyway (unit edge values, COO rows, not disabled).
+inline bool plan_usable(const Plan &p, int f, bool unit_val, const int *rows) {
+  if (block_width_ok(f)) return true;
+  return f == 8 && unit_val && rows && dense_enabled() && p.num_dense == p.num_fit;
+}
+
 // Returns <0 on a bad argument, 1 when there is nothing to do, 0 to proceed.
 inline int check_common(int m, int nnz, int h, int f, const void *row_ptr, const void *col_ind) {
   if (m < 0 || nnz < 0 || h < 0 || f < 0) return kErrBadArg;
@@ -56,7 +63,7 @@ int dfgnn_gt_hyper_fwd(int m, int nnz, int h, int f, const int *row_ptr, const i
   const Csr g{m, nnz, h, f, row_ptr, col_ind, rows, val};
   Plan p;
   const bool v4 = (f % 4 == 0) && aligned16(Q) && aligned16(K) && aligned16(V) && aligned16(out);
-  if (v4 && block_width_ok(f) && make_plan(p, plan, plan_meta, m, nnz, f)) {
+  if (v4 && make_plan(p, plan, plan_meta, m, nnz, f) && plan_usable(p, f, !val, rows)) {
     if (int rc = launch_gt_block_fwd(g, p, Q, K, V, attn_edge, edge_ws, out, as_stream(stream))) return rc;
     return launch_gt_hyper_fwd(g, Q, K, V, attn_edge, out, p.spill(), p.num_spill, as_stream(stream));
   }
@@ -101,7 +108,7 @@ int dfgnn_gt_bwd(int m, int nnz, int h, int f, const int *row_ptr, const int *co
                   aligned16(dQ) && aligned16(dK) && aligned16(dV);
   const int *chunks = nullptr;
   int nchunks = 0;
-  if (v4 && block_width_ok(f) && make_plan(p, plan, plan_meta, m, nnz, f)) {
+  if (v4 && make_plan(p, plan, plan_meta, m, nnz, f) && plan_usable(p, f, !val, rows)) {
     if (int rc = launch_gt_block_bwd(g, p, col_ptr, row_ind, val_idx, Q, K, V, attn_edge, grad_out, grad_edge, dQ,
                                      dK, dV, as_stream(stream)))
       return rc;
@@ -156,7 +163,7 @@ int dfgnn_gat_hyper_fwd(int m, int nnz, int h, int f, const int *row_ptr, const 
   const Csr g{m, nnz, h, f, row_ptr, col_ind, rows, nullptr};
   Plan p;
   const bool v4 = (f % 4 == 0) && aligned16(X) && aligned16(out);
-  if (v4 && block_width_ok(f) && make_plan(p, plan, plan_meta, m, nnz, f)) {
+  if (v4 && make_plan(p, plan, plan_meta, m, nnz, f) && plan_usable(p, f, true, rows)) {
     if (int rc = launch_gat_block_fwd(g, p, attn_row, attn_col, negative_slope, X, edge_ws, out, as_stream(stream)))
       return rc;
     return launch_gat_hyper_fwd(g, attn_row, attn_col, negative_slope, X, out, p.spill(), p.num_spill,
@@ -212,7 +219,7 @@ int dfgnn_gat_attn_scores(int m, int h, int f, const float *a_l, const float *a_
 static bool gat_train_dense(Plan &p, const int *rows, const int *plan, const int *plan_meta, int m, int nnz, int f,
                             bool v4) {
   if (!rows || !v4 || !dense_enabled()) return false;
-  if (f != 16 && f != 32 && f != 64 && f != 128) return false;
+  if (f != 8 && f != 16 && f != 32 && f != 64 && f != 128) return false;
   if (!make_plan(p, plan, plan_meta, m, nnz, f)) return false;
   return p.num_dense > 0;
 }

@@ -876,7 +876,8 @@ bool dense_enabled() {
 
 template <class Fn>
 static int dispatch_dense(int f, Fn &&fn) {
-  if (f == 16) return fn(std::integral_constant<int, 16>{});  // zero-padded onto the 32-wide layout
+  if (f == 8) return fn(std::integral_constant<int, 8>{});    // f = 8 / 16: zero-padded onto the 32-wide layout
+  if (f == 16) return fn(std::integral_constant<int, 16>{});
   if (f == 32) return fn(std::integral_constant<int, 32>{});
   if (f == 64) return fn(std::integral_constant<int, 64>{});
   if (f == 128) return fn(std::integral_constant<int, 128>{});

@@ -148,7 +148,7 @@ __global__ __launch_bounds__(kPlanThreads) void plan_cut_kernel(int m, int nnz, 
   int *fit = plan + kPlanHeader;
   int *spill = fit + 2 * (size_t)m;
   const int t = threadIdx.x;
-  const bool dense_f = (f == 16 || f == 32 || f == 64 || f == 128);
+  const bool dense_f = (f == 8 || f == 16 || f == 32 || f == 64 || f == 128);
   // rows with a duplicate edge before row `end`
   auto bad_before = [&](int end) { return end > 0 ? pairs[end - 1].bad : 0; };
   // a fit entry (n0, n1 | flags) for the range [n0, n1) holding ed edges; returns its flags
@@ -416,7 +416,7 @@ int dfgnn_plan_build(int m, int nnz, int f, const int *row_ptr, const int *col_i
     return (int)rc;
   // Widths with a matrix-core form: a merged range costs n^2 there and needs a second pass over 128-row blocks past
   // 128 nodes, so small graphs are only merged up to 128 nodes.
-  const int merge_nodes = (f == 16 || f == 32 || f == 64 || f == 128) ? 128 : kBlockMergeNodes;
+  const int merge_nodes = (f == 8 || f == 16 || f == 32 || f == 64 || f == 128) ? 128 : kBlockMergeNodes;
   constexpr size_t kCutLds = sizeof(int) * (3 * (kPlanCache + 1) + kPlanCache + 2 * kPlanThreads) + 2 * kPlanCache;
   static_assert(kCutLds <= (size_t)kLdsBytes, "plan_cut_kernel LDS");
   if (hipError_t rc = hipFuncSetAttribute(reinterpret_cast<const void *>(plan_cut_kernel),

@@ -52,7 +52,7 @@ const char *dfgnn_error_string(int code);
  * everything else into 16-row chunks for the general kernels.  Results are identical with or
  * without a plan.  The plan depends on the graph structure and on f only; build it once per batch
  * (it belongs to preprocessing, like the reference's preprocess_Hyper, DFGNN/layers/util.py:82-100).
- * Ranges that are dense (>= 1 edge per 32 node pairs), have at most 255 nodes, f in {16, 32, 64, 128} and no
+ * Ranges that are dense (>= 1 edge per 32 node pairs), have at most 255 nodes, f in {8, 16, 32, 64, 128} and no
  * duplicate edges are additionally marked for the matrix-core kernels, which the GT
  * forward / backward use for them when val == NULL (unit edge values): masked dense attention on MFMA,
  * split-bf16 operands with fp32 accumulation (~2^-16 relative error per product).

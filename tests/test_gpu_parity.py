@@ -338,14 +338,15 @@ def test_block_plan_structure():
     assert set(np.cumsum(sizes)).issuperset(set(fit[:, 1]))                              # = graph boundaries
     assert maxn == (fit[:, 1] - fit[:, 0]).max() and maxn <= 256
     assert maxe == (rp[fit[:, 1]] - rp[fit[:, 0]]).max()
-    # f = 8: no matrix-core form; many graphs merge into one block of <= 256 nodes
-    plan8 = build_plan(row_ptr, col_ind, 8)
-    fit8 = plan8.buf.cpu().numpy()[12:12 + 2 * plan8.meta[0]].reshape(-1, 2) & ~FLAGS
-    assert plan8.num_dense == 0
-    assert plan8.meta[0] < nfit and (fit8[:, 1] - fit8[:, 0]).max() <= 256
-    # f = 16 runs zero-padded on the 32-wide matrix-core instance: same classification as f = 128
-    plan16 = build_plan(row_ptr, col_ind, 16)
-    assert plan16.num_dense == nd and plan16.meta[0] == nfit
+    # f = 4: no matrix-core form; many graphs merge into one block of <= 256 nodes
+    plan4 = build_plan(row_ptr, col_ind, 4)
+    fit4 = plan4.buf.cpu().numpy()[12:12 + 2 * plan4.meta[0]].reshape(-1, 2) & ~FLAGS
+    assert plan4.num_dense == 0
+    assert plan4.meta[0] < nfit and (fit4[:, 1] - fit4[:, 0]).max() <= 256
+    # f = 8 / 16 run zero-padded on the 32-wide matrix-core layout: same classification as f = 128
+    for fp in (8, 16):
+        planp = build_plan(row_ptr, col_ind, fp)
+        assert planp.num_dense == nd and planp.meta[0] == nfit
     # a full graph is one closed range that cannot fit: everything spills in <= 16-row chunks
     c = S.cora_like()
     rp2, ci2, _, _, _ = preprocess_Hyper(c.to(DEV))
@@ -414,7 +415,7 @@ def test_block_kernels_match_oracle_and_general_path(oracle_mod, h, f, bs, unit_
     assert torch.allclose(out_b, out_n, atol=1e-5, rtol=1e-4)
 
 
-@pytest.mark.parametrize("h,f", [(1, 128), (2, 64), (3, 32), (4, 16)])
+@pytest.mark.parametrize("h,f", [(1, 128), (2, 64), (3, 32), (4, 16), (2, 8)])
 def test_dense_kernels_every_geometry(oracle_mod, h, f):
     """Matrix-core kernels (gt_dense.hip) vs the oracle on a batch whose ranges hit every code path: tiny graphs
     (1 strip), <= 128 nodes (one tile), 129-160 nodes (160-row images, two row blocks), 161-255 nodes (2 x 2 tiles),
@@ -622,7 +623,7 @@ def test_gat_train_pattern_like_batch(oracle_mod):
 
 
 @pytest.mark.parametrize("attn_drop", [0.0, 0.4])
-@pytest.mark.parametrize("h,f", [(1, 128), (2, 64), (3, 32), (4, 16)])
+@pytest.mark.parametrize("h,f", [(1, 128), (2, 64), (3, 32), (4, 16), (2, 8)])
 def test_gat_train_dense_every_geometry(oracle_mod, h, f, attn_drop):
     """GAT training pair on the matrix-core kernels (gat_dense_fwd_kernel with row statistics, gat_dense_bwd_kernel): a
     batch whose ranges are all dense and hit every geometry (1 strip, <= 128 nodes, 129-160 nodes with two row blocks,
@@ -898,7 +899,7 @@ def _reference_plan(row_ptr, col_ind, f, budget, merge_nodes):
         dup[i + 1] = dup[i] + bad
     lite = lambda n, e: min(n, 1 << 16) * (4 * f + 8) + min(e, 1 << 24) * (1 if min(n, 1 << 16) <= 256 else 2)  # noqa: E731
     full = lambda n, e: lite(n, e) + 4 * min(e, 1 << 24)  # noqa: E731
-    dense_f = f in (16, 32, 64, 128)
+    dense_f = f in (8, 16, 32, 64, 128)
     fit, spill = [], []
 
     def flush(n0, n1):
@@ -1008,3 +1009,34 @@ def test_harness_scripts_run_like_the_reference(capsys):
     # the reference's relative-only verdict may trip on near-zero elements of the matrix-core formats;
     # whenever it does, the difference must still be inside the 1e-3 parity bar
     assert out.count("mismatch") == out.count("inside the 1e-3 parity bar")
+
+
+@pytest.mark.parametrize("h,f", [(8, 16), (8, 8), (4, 16)])
+def test_multihead_small_width_on_matrix_cores(oracle_mod, h, f):
+    """Multi-head GT with narrow heads (dim 128 / 8 heads, dim 64 / 8 heads): f = 16 and f = 8 run zero-padded on the
+    32-wide matrix-core layout.  fwd + bwd against the oracle on an all-dense batch, and against the general kernels."""
+    import fused_gtconv as gt
+    from DFGNN.layers import preprocess_Hyper_fw_bw
+    from DFGNN.utils import synthetic as S
+    g = S.pattern_like(batch_size=20, seed=11).to(DEV)
+    A, rows, row_ptr, col_ind, val, col_ptr, row_ind, val_idx, smem = preprocess_Hyper_fw_bw(g)
+    m = g.num_nodes()
+    Q, K, V = S.gt_features(m, h, f, seed=5, device=DEV)
+    dO = torch.randn(m, h, f, generator=torch.Generator().manual_seed(3)).to(DEV)
+    args = (row_ptr, col_ind, rows, val, col_ptr, row_ind, val_idx, smem, Q, K, V)
+    out, attn = gt.gt_hyper_forward(*args)
+    plan = row_ptr._dfgnn_plans[f]
+    assert plan.num_dense == plan.num_fit > 0 and plan.num_spill == 0
+    dQ, dK, dV = gt.gt_backward(*args, attn, dO)
+    n_ = lambda t: t.cpu().numpy()  # noqa: E731
+    want, want_attn = oracle_mod.gt_forward(n_(row_ptr), n_(col_ind), n_(val), n_(Q), n_(K), n_(V), want_attn=True)
+    wq, wk, wv = oracle_mod.gt_backward(n_(row_ptr), n_(col_ind), n_(val), n_(Q), n_(K), n_(V), n_(dO))
+    for got, ref, what in ((out, want, "out"), (attn, want_attn, "attn_edge"), (dQ, wq, "dQ"), (dK, wk, "dK"), (dV, wv, "dV")):
+        _close(got, ref, f"h={h} f={f} {what}")
+    _close(gt.gt_hyper_inference(row_ptr, col_ind, rows, val, smem, Q, K, V)[0], want, "inference")
+    gt.USE_BLOCK_PLAN = False
+    try:
+        out_n, attn_n = gt.gt_hyper_forward(*args)
+    finally:
+        gt.USE_BLOCK_PLAN = True
+    assert torch.allclose(out, out_n, atol=2e-4, rtol=1e-3) and not torch.equal(out, out_n)   # two code paths
