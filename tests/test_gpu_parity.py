@@ -701,7 +701,7 @@ def test_gat_train_dense_every_geometry(oracle_mod, h, f, attn_drop):
     torch.manual_seed(5)
     out2, emax2, esum2, mask2 = gat.gat_forward(ar, ac, row_ptr, col_ind, 0.2, X, attn_drop)
     p2 = row_ptr._dfgnn_plans[f]
-    assert 0 < p2.num_dense < p2.num_fit and p2.num_spill > 0
+    assert 0 < p2.num_dense < p2.num_fit and (p2.num_spill > 0 or f < 32)   # (narrow rows: the big graph still fits LDS)
     gf2, gr2, gc2 = gat.gat_backward(0.2, attn_drop, row_ptr, col_ind, col_ptr, row_ind, val_idx, emax2, esum2, mask2, X,
                                      ar, ac, dO)
     args2 = (n_(row_ptr), n_(col_ind), n_(ar), n_(ac), 0.2, n_(X))
