@@ -156,3 +156,50 @@ def test_loader_brings_torch_in_first():
             "n.lib(); assert 'torch' in sys.modules; print('ok')" % (ROOT + "/df-gnn_amd"))
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
+
+
+def test_synthetic_datasets_and_loader():
+    """DFGNN.utils.datasets: the stand-ins for load_dataset_fn / load_data_full_graph / GraphDataLoader behave like the
+    objects the reference's scripts expect (block-diagonal batches, ndata['feat'], deterministic items)."""
+    from DFGNN.utils import GraphDataLoader, load_data_full_graph, load_dataset_fn
+    ds, infer = load_dataset_fn("PATTERN", None, length=7)
+    assert len(ds) == 7 and callable(infer)
+    g0, y0 = ds[0]
+    g0b, _ = ds[0]
+    assert torch.equal(g0.edges()[0], g0b.edges()[0]) and torch.equal(g0.ndata["feat"], g0b.ndata["feat"])
+    batches = list(GraphDataLoader(ds, batch_size=3))
+    assert len(batches) == 3 and [len(y) for _, y in batches] == [3, 3, 1]
+    bg, _ = batches[0]
+    sizes = [ds[i][0].num_nodes() for i in range(3)]
+    assert bg.num_nodes() == sum(sizes) and bg.ndata["feat"].shape == (sum(sizes), 64)
+    src, dst = bg.edges()
+    off = np.cumsum([0] + sizes)
+    gid = np.searchsorted(off, src.numpy(), side="right")
+    assert (gid == np.searchsorted(off, dst.numpy(), side="right")).all()      # no edge crosses a member graph
+    with pytest.raises(ValueError):
+        load_dataset_fn("ogbg-molhiv", None)
+    cora = load_data_full_graph("cora")
+    assert cora.num_nodes() == 2708 and cora.ndata["feat"].shape[0] == 2708
+    with pytest.raises(NotImplementedError):
+        GraphDataLoader(ds, batch_size=2, shuffle=True)
+
+
+def test_check_correct_follows_the_reference_rule(capsys):
+    """isclose(rtol=1e-3) per element, a row with exactly one miss passes, every failing row is examined
+    (DFGNN/utils/util.py:211-236 of the reference); a relative-only miss inside the 1e-3 bar says so."""
+    a = torch.randn(6, 8)
+    b = a.clone()
+    assert check_correct(a, b)
+    b[1, 2] += 1.0
+    b[4, 0] += 1.0                                   # two rows with a single miss each: tolerated
+    assert check_correct(a, b)
+    b[4, 5] += 1.0                                   # second miss in row 4
+    assert not check_correct(a, b)
+    assert "error node 4 mismatch" in capsys.readouterr().out
+    c = torch.zeros(3, 4)
+    c[:, 0] = 1.0
+    d = c.clone()
+    d[2, 1] = 3e-6
+    d[2, 2] = -2e-6                                  # near-zero elements: relative check trips, absolute error tiny
+    assert not check_correct(c, d)
+    assert "inside the 1e-3 parity bar" in capsys.readouterr().out
