@@ -45,6 +45,11 @@ extern "C" {
 
 int dfgnn_abi_version(void) { return DFGNN_ABI_VERSION; }
 
+#ifndef DFGNN_SRC_HASH
+#define DFGNN_SRC_HASH "unknown"
+#endif
+const char *dfgnn_build_id(void) { return DFGNN_SRC_HASH; }
+
 const char *dfgnn_error_string(int code) {
   if (code == 0) return "success";
   if (code == DFGNN_E_BADARG) return "dfgnn: bad argument (negative size or NULL required pointer)";

@@ -212,24 +212,7 @@ __device__ __forceinline__ void block_spmm(Frag<C> &acc, const float *res, int2 
   }
 }
 
-// ---- matrix-core logits (split-bf16) -----------------------------------------------------------------------------
-// The dense per-head feature contraction of a range, S = Q K^T, on MFMA: fp32 operands are split into two bf16
-// halves (x = hi + lo, |x - hi - lo| <= 2^-17 |x|) and  S ~= Qhi Khi^T + Qhi Klo^T + Qlo Khi^T  is accumulated in fp32
-// by v_mfma_f32_16x16x32_bf16 (relative error ~2^-16 per product, far inside the 1e-3 parity bar; the dropped
-// lo*lo term is ~2^-18).  One 16x16 tile costs 3 * F/32 MFMAs of 16 cycles instead of ~40 VALU wave-instructions
-// per 16 *edges*; the sparse structure is applied afterwards by gathering each row's edge logits from the tile panel.
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
-
-__device__ __forceinline__ void split_bf16x8(const float4 &a, const float4 &b, bf16x8 &hi, bf16x8 &lo) {
-  const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const __bf16 h = (__bf16)x[j];
-    hi[j] = h;
-    lo[j] = (__bf16)(x[j] - (float)h);
-  }
-}
 
 size_t block_lds_bytes(const Plan &p, int f);
 

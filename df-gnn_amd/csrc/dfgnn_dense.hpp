@@ -7,13 +7,17 @@
 // ranges that have at least one edge per 32 node pairs, at most 255 nodes and no duplicate edges as "dense"; with
 // unit edge values they are served by the kernels of gt_dense.hip, everything else by the edge-walking kernels.
 //
-// Numerics: fp32 operands are split into two bf16 halves (x = hi + lo, |x - hi - lo| <= 2^-17 |x|) and a product
-// X Y is accumulated in fp32 as Xhi Yhi + Xhi Ylo + Xlo Yhi on v_mfma_f32_16x16x32_bf16 (relative error ~2^-16 per
-// product -- inside the 1e-3 parity bar by 60x; the dropped lo*lo term is ~2^-18).
+// Numerics (fp32-equivalent): every operand is multiplied by a power of two that brings the largest magnitude of its
+// image / strip / tile into [2^14, 2^15) and split into two fp16 halves, x s = hi + lo with hi = rn16(x s),
+// lo = rn16(x s - hi): |x s - hi - lo| <= 2^-24 |x s| for every element within 2^-17 of the maximum (below that the
+// error is the fp16 subnormal spacing, 2^-39 of the maximum).  A product X Y is accumulated in fp32 as
+// Xhi Yhi + Xhi Ylo + Xlo Yhi on v_mfma_f32_16x16x32_f16 (the dropped lo lo term is <= 2^-24 of the product) and the
+// result is multiplied by the inverse powers of two, which is exact: the error per product is ~3 x 2^-24, that of an
+// fp32 FMA chain of the same length.  (The first version used bf16 halves: 16 significant bits, no scaling.)
 //
-// Layouts.  A feature matrix is staged 128 rows at a time as a row-major bf16 "image" (hi and lo copies, rows
+// Layouts.  A feature matrix is staged 128 rows at a time as a row-major fp16 "image" (hi and lo copies, rows
 // skewed by 16 elements so that both the 16-byte row reads and the transposed reads are bank-conflict free).
-// For v_mfma_f32_16x16x32_bf16, lane l = (mi = l & 15, mq = l >> 4) holds A[row mi][k = 8 mq + t] and
+// For v_mfma_f32_16x16x32_f16, lane l = (mi = l & 15, mq = l >> 4) holds A[row mi][k = 8 mq + t] and
 // B[k = 8 mq + t][col mi] in element t, and D[row 4 mq + r][col mi] in register r.
 //   * rows of an image as the A operand: one 16-byte read per k-step  ->  D^T tiles (rows = image rows, cols = the
 //     16 rows of the register operand), i.e. a wave that owns 16 rows i ("strip") of S = Q K^T gets S[i][j] for its
@@ -27,8 +31,37 @@
 
 namespace dfgnn {
 
-typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
-typedef __attribute__((address_space(3))) bf16x4 *lds_bf16x4_ptr;
+typedef _Float16 h16;                                         // operand halves
+typedef __attribute__((ext_vector_type(8))) _Float16 hx8;
+typedef __attribute__((ext_vector_type(4))) _Float16 hx4;
+typedef __fp16 fp16x4_raw __attribute__((__vector_size__(4 * sizeof(__fp16))));  // the transposed-read builtin's type
+typedef __attribute__((address_space(3))) fp16x4_raw *lds_hx4_ptr;
+
+// Power-of-two scale of an operand whose largest magnitude is amax: s amax lies in [2^14, 2^15), inv = 1 / s.
+// (amax = 0 or subnormal: the largest normal scale; inf / nan inputs give inf / nan outputs, as in fp32.)
+struct Pow2Scale {
+  float s, inv;
+};
+__device__ __forceinline__ Pow2Scale pow2_scale(float amax) {  // amax must be wave-uniform: the result lives in SGPRs
+  const int b = min(max((__builtin_amdgcn_readfirstlane(__float_as_int(amax)) >> 23) & 0xFF, 15), 254);  // biased exponent
+  return Pow2Scale{__int_as_float((268 - b) << 23), __int_as_float((b - 14) << 23)};
+}
+constexpr float kUnitScale = 16384.f, kUnitScaleInv = 1.f / 16384.f;  // for operands known to lie in [0, 1]
+
+// x s -> fp16 hi / lo halves (v_pk_mul_f32, v_cvt_pk_f16_f32, v_cvt_f32_f16, v_pk_fma_f32, v_cvt_pk_f16_f32)
+__device__ __forceinline__ void split_hx8(const float4 &a, const float4 &b, float s, hx8 &hi, hx8 &lo) {
+  const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const h16 h = (h16)(x[j] * s);
+    hi[j] = h;
+    lo[j] = (h16)fmaf(x[j], s, -(float)h);
+  }
+}
+__device__ __forceinline__ float absmax8(const float4 &a, const float4 &b) {
+  return fmaxf(fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w))),
+               fmaxf(fmaxf(fabsf(b.x), fabsf(b.y)), fmaxf(fabsf(b.z), fabsf(b.w))));
+}
 
 constexpr int kDenseThreads = 512;                    // 8 waves: up to 256 VGPRs each, one workgroup per CU (LDS)
 constexpr int kDenseWaves = kDenseThreads / kWave;
@@ -38,7 +71,7 @@ constexpr int kDensePre = 16;                         // edges per thread fetche
 
 template <int F>
 struct DenseCfg {
-  static constexpr int RS = F + 16;  // bf16 elements per image row
+  static constexpr int RS = F + 16;  // fp16 elements per image row
   static constexpr int KT = F / 32;  // MFMA k-steps across the feature dimension
   static constexpr int FT = F / 16;  // 16-feature tiles of the output
 };
@@ -74,7 +107,7 @@ __device__ __forceinline__ LaneIds lane_ids() {
 }
 
 // ---- feature images -----------------------------------------------------------------------------------------------
-// ROWS rows x F features: global -> registers (issued one phase ahead of its use) -> bf16 hi / lo images in LDS.
+// ROWS rows x F features: global -> registers (issued one phase ahead of its use) -> fp16 hi / lo images in LDS.
 template <int F, int ROWS>
 struct DenseStageRegs {
   static constexpr int PER = (ROWS * (F / 8) + kDenseThreads - 1) / kDenseThreads;  // 8-float pieces per thread
@@ -104,13 +137,36 @@ __device__ __forceinline__ void dense_stage_load(DenseStageRegs<F, ROWS> &r, con
   }
 }
 
+// Largest magnitude this thread holds of the image that is about to be stored.  (Clamped loads repeat valid rows and
+// pieces, so nothing needs masking.)
+template <int F, int ROWS>
+__device__ __forceinline__ float dense_stage_absmax(const DenseStageRegs<F, ROWS> &r) {
+  float m = 0.f;
+#pragma unroll
+  for (int k = 0; k < DenseStageRegs<F, ROWS>::PER; ++k) m = fmaxf(m, absmax8(r.a[k], r.b[k]));
+  return m;
+}
+
+// Workgroup-wide maximum through an 8-entry LDS array: every wave posts its own maximum BEFORE a workgroup barrier the
+// caller already has, every thread reads all of them after it.  `slot` must not be posted to again before another
+// barrier has passed (every caller has one: the barrier that publishes what was converted with the result).
+__device__ __forceinline__ void wg_max_post(float *slot, float v) {
+  v = wave_max(v);
+  if ((threadIdx.x & (kWave - 1)) == 0) slot[threadIdx.x / kWave] = v;
+}
+__device__ __forceinline__ float wg_max_read(const float *slot) {
+  const float4 a = *reinterpret_cast<const float4 *>(slot), b = *reinterpret_cast<const float4 *>(slot + 4);
+  return fmaxf(fmaxf(fmaxf(a.x, a.y), fmaxf(a.z, a.w)), fmaxf(fmaxf(b.x, b.y), fmaxf(b.z, b.w)));
+}
+
 // The trailing memory clobber keeps the loads of the next prefetch (usually into these same registers) from being
 // interleaved with the stores piece by piece: memory returns in order, so each piece would then wait for the loads
-// that were just issued.  (Pinning the bf16 conversion here with an empty asm, so that the scheduler cannot hoist it
+// that were just issued.  (Pinning the conversion here with an empty asm, so that the scheduler cannot hoist it
 // and the wait for the data to the previous barrier, measured 2 % slower.)
 // fr: real feature count (<= F, a multiple of 8): the image columns at or past it are stored as zeros.
+// scale: the image's power-of-two scale (pow2_scale of its largest magnitude).
 template <int F, int ROWS>
-__device__ __forceinline__ void dense_stage_store(DenseStageRegs<F, ROWS> &r, __bf16 *hi, __bf16 *lo, int fr = F) {
+__device__ __forceinline__ void dense_stage_store(DenseStageRegs<F, ROWS> &r, h16 *hi, h16 *lo, float scale, int fr = F) {
   constexpr int C8 = F / 8, RS = DenseCfg<F>::RS;
   const int tid = opaque_tid();
 #pragma unroll
@@ -120,62 +176,43 @@ __device__ __forceinline__ void dense_stage_store(DenseStageRegs<F, ROWS> &r, __
     if (idx < ROWS * C8) {
       const bool valid = r.row0 + row < r.row_end && (fr >= F || 8 * c8 < fr);
       const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-      bf16x8 h, l;
-      split_bf16x8(valid ? r.a[k] : z, valid ? r.b[k] : z, h, l);
-      *reinterpret_cast<bf16x8 *>(hi + row * RS + 8 * c8) = h;
-      *reinterpret_cast<bf16x8 *>(lo + row * RS + 8 * c8) = l;
+      hx8 h, l;
+      split_hx8(valid ? r.a[k] : z, valid ? r.b[k] : z, scale, h, l);
+      *reinterpret_cast<hx8 *>(hi + row * RS + 8 * c8) = h;
+      *reinterpret_cast<hx8 *>(lo + row * RS + 8 * c8) = l;
     }
   }
   asm volatile("" ::: "memory");
 }
 
-// 16 rows of a matrix as the register operand of D^T = Image . X^T: lane (mi, mq) holds X[row][32 t + 8 mq ..] for
-// its row (`valid` = false zeroes it; `row` must still be a row of the range)
-template <int F>
-__device__ __forceinline__ void dense_row_operand(bf16x8 (&xh)[F / 32], bf16x8 (&xl)[F / 32], const float *__restrict__ base,
-                                                  size_t hf, int row, bool valid, const LaneIds &L) {
-  const unsigned off = (unsigned)row * (unsigned)hf + 8u * L.mq;
-  float4 a[F / 32], b[F / 32];
-#pragma unroll
-  for (int t = 0; t < F / 32; ++t) {  // all loads first: a conversion in between would wait for each piece in turn
-    a[t] = ld32_f4(base, off + 32 * t);
-    b[t] = ld32_f4(base, off + 32 * t + 4);
-  }
-#pragma unroll
-  for (int t = 0; t < F / 32; ++t) {
-    if (!valid) a[t] = b[t] = make_float4(0.f, 0.f, 0.f, 0.f);
-    split_bf16x8(a[t], b[t], xh[t], xl[t]);
-  }
-}
-
 // D^T tile u (image rows 16 u .. 16 u + 15) against a register row operand: 3 * F/32 MFMAs
 template <int F>
-__device__ __forceinline__ void dense_rows_frag(bf16x8 (&ah)[F / 32], bf16x8 (&al)[F / 32], const __bf16 *ihi,
-                                                const __bf16 *ilo, int u, const LaneIds &L) {
+__device__ __forceinline__ void dense_rows_frag(hx8 (&ah)[F / 32], hx8 (&al)[F / 32], const h16 *ihi,
+                                                const h16 *ilo, int u, const LaneIds &L) {
   constexpr int RS = DenseCfg<F>::RS;
   const int off = (16 * u + L.mi) * RS + 8 * L.mq;
 #pragma unroll
   for (int t = 0; t < F / 32; ++t) {
-    ah[t] = *reinterpret_cast<const bf16x8 *>(ihi + off + 32 * t);
-    al[t] = *reinterpret_cast<const bf16x8 *>(ilo + off + 32 * t);
+    ah[t] = *reinterpret_cast<const hx8 *>(ihi + off + 32 * t);
+    al[t] = *reinterpret_cast<const hx8 *>(ilo + off + 32 * t);
   }
 }
 template <int F>
-__device__ __forceinline__ f32x4 dense_rows_mma_frag(const bf16x8 (&ah)[F / 32], const bf16x8 (&al)[F / 32],
-                                                     const bf16x8 (&xh)[F / 32], const bf16x8 (&xl)[F / 32]) {
+__device__ __forceinline__ f32x4 dense_rows_mma_frag(const hx8 (&ah)[F / 32], const hx8 (&al)[F / 32],
+                                                     const hx8 (&xh)[F / 32], const hx8 (&xl)[F / 32]) {
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int t = 0; t < F / 32; ++t) {
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[t], xh[t], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[t], xl[t], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[t], xh[t], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], xh[t], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], xl[t], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[t], xh[t], acc, 0, 0, 0);
   }
   return acc;
 }
 template <int F>
-__device__ __forceinline__ f32x4 dense_rows_mma(const __bf16 *ihi, const __bf16 *ilo, int u, const bf16x8 (&xh)[F / 32],
-                                                const bf16x8 (&xl)[F / 32], const LaneIds &L) {
-  bf16x8 ah[F / 32], al[F / 32];
+__device__ __forceinline__ f32x4 dense_rows_mma(const h16 *ihi, const h16 *ilo, int u, const hx8 (&xh)[F / 32],
+                                                const hx8 (&xl)[F / 32], const LaneIds &L) {
+  hx8 ah[F / 32], al[F / 32];
   dense_rows_frag<F>(ah, al, ihi, ilo, u, L);
   return dense_rows_mma_frag<F>(ah, al, xh, xl);
 }
@@ -183,10 +220,10 @@ __device__ __forceinline__ f32x4 dense_rows_mma(const __bf16 *ihi, const __bf16 
 // D^T tiles 0 .. NTILES-1 of the resident image (those with 16 u < limit; the others are zero) against a register
 // row operand, the image fragments of tile u + 1 being fetched while tile u is multiplied
 template <int F, int NTILES>
-__device__ __forceinline__ void dense_rows_mma_strip(f32x4 (&out)[NTILES], const __bf16 *ihi, const __bf16 *ilo, int limit,
-                                                     const bf16x8 (&xh)[F / 32], const bf16x8 (&xl)[F / 32],
+__device__ __forceinline__ void dense_rows_mma_strip(f32x4 (&out)[NTILES], const h16 *ihi, const h16 *ilo, int limit,
+                                                     const hx8 (&xh)[F / 32], const hx8 (&xl)[F / 32],
                                                      const LaneIds &L) {
-  bf16x8 ah[2][F / 32], al[2][F / 32];
+  hx8 ah[2][F / 32], al[2][F / 32];
   dense_rows_frag<F>(ah[0], al[0], ihi, ilo, 0, L);
 #pragma unroll
   for (int u = 0; u < NTILES; ++u) {
@@ -196,20 +233,20 @@ __device__ __forceinline__ void dense_rows_mma_strip(f32x4 (&out)[NTILES], const
 }
 
 // Two transposed 4-row reads -> one 8-element operand fragment (rows r .. r+3 and r + second .. of a column).
-__device__ __forceinline__ bf16x8 dense_tr_pair(const __bf16 *p, int second_offset) {
-  const bf16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(p));
-  const bf16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(p + second_offset));
+__device__ __forceinline__ hx8 dense_tr_pair(const h16 *p, int second_offset) {
+  const hx4 a = __builtin_bit_cast(hx4, __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_hx4_ptr)(p)));
+  const hx4 b = __builtin_bit_cast(hx4, __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_hx4_ptr)(p + second_offset)));
   return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-// 8 fp32 values -> bf16 hi / lo operand fragments
-__device__ __forceinline__ void dense_split8(const f32x4 &x0, const f32x4 &x1, bf16x8 &h, bf16x8 &l) {
+// 8 fp32 values x scale -> fp16 hi / lo operand fragments
+__device__ __forceinline__ void dense_split8(const f32x4 &x0, const f32x4 &x1, float scale, hx8 &h, hx8 &l) {
 #pragma unroll
   for (int t = 0; t < 8; ++t) {
     const float x = (t < 4) ? x0[t] : x1[t - 4];
-    const __bf16 hh = (__bf16)x;
+    const h16 hh = (h16)(x * scale);
     h[t] = hh;
-    l[t] = (__bf16)(x - (float)hh);
+    l[t] = (h16)fmaf(x, scale, -(float)hh);
   }
 }
 
@@ -219,34 +256,34 @@ __device__ __forceinline__ void dense_split8(const f32x4 &x0, const f32x4 &x1, b
 // are issued as three sweeps over that many independent accumulators, so neither the LDS latency nor the MFMA result latency
 // serialises the chain.
 template <int F, int GMAX = 4>
-__device__ __forceinline__ void dense_kblock_mma(f32x4 (&acc)[F / 16], const __bf16 *ihi, const __bf16 *ilo, int xoff,
-                                                 int second, const bf16x8 &yh, const bf16x8 &yl) {
+__device__ __forceinline__ void dense_kblock_mma(f32x4 (&acc)[F / 16], const h16 *ihi, const h16 *ilo, int xoff,
+                                                 int second, const hx8 &yh, const hx8 &yl) {
   constexpr int FT = F / 16, G = FT < GMAX ? FT : GMAX;
 #pragma unroll
   for (int f0 = 0; f0 < FT; f0 += G) {
-    bf16x8 xh[G], xl[G];
+    hx8 xh[G], xl[G];
 #pragma unroll
     for (int k = 0; k < G; ++k) {
       xh[k] = dense_tr_pair(ihi + xoff + 16 * (f0 + k), second);
       xl[k] = dense_tr_pair(ilo + xoff + 16 * (f0 + k), second);
     }
 #pragma unroll
-    for (int k = 0; k < G; ++k) acc[f0 + k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh[k], yh, acc[f0 + k], 0, 0, 0);
+    for (int k = 0; k < G; ++k) acc[f0 + k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh[k], yh, acc[f0 + k], 0, 0, 0);
 #pragma unroll
-    for (int k = 0; k < G; ++k) acc[f0 + k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xl[k], yh, acc[f0 + k], 0, 0, 0);
+    for (int k = 0; k < G; ++k) acc[f0 + k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xl[k], yh, acc[f0 + k], 0, 0, 0);
 #pragma unroll
-    for (int k = 0; k < G; ++k) acc[f0 + k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh[k], yl, acc[f0 + k], 0, 0, 0);
+    for (int k = 0; k < G; ++k) acc[f0 + k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh[k], yl, acc[f0 + k], 0, 0, 0);
   }
 }
 
 // acc[ft] += Image^T (features 16 ft .., image rows 32 jb ..) . Y, Y given as the accumulator pair (y0, y1) of a
-// D^T strip (permuted k order, see the header): the "P V" product of the forward
+// D^T strip (permuted k order, see the header): the "P V" product of the forward.  yscale: power-of-two scale of Y.
 template <int F, int GMAX = 4>
-__device__ __forceinline__ void dense_cols_mma(f32x4 (&acc)[F / 16], const __bf16 *ihi, const __bf16 *ilo, int jb,
-                                               const f32x4 &y0, const f32x4 &y1, const LaneIds &L) {
+__device__ __forceinline__ void dense_cols_mma(f32x4 (&acc)[F / 16], const h16 *ihi, const h16 *ilo, int jb,
+                                               const f32x4 &y0, const f32x4 &y1, float yscale, const LaneIds &L) {
   constexpr int RS = DenseCfg<F>::RS;
-  bf16x8 yh, yl;
-  dense_split8(y0, y1, yh, yl);
+  hx8 yh, yl;
+  dense_split8(y0, y1, yscale, yh, yl);
   dense_kblock_mma<F, GMAX>(acc, ihi, ilo, (32 * jb + 4 * L.mq + L.tq) * RS + 4 * L.tp, 16 * RS, yh, yl);
 }
 

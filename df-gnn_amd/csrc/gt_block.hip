@@ -40,27 +40,8 @@ __global__ __launch_bounds__(kBlockThreads) void gt_block_fwd_kernel(Csr g, cons
   const int ne = g.row_ptr[n1] - e0;
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
   const int gid = lane / G, gl = lane % G;
-  // Matrix-core logits (dfgnn_block.hpp): K lives in LDS as two bf16 halves, rows padded to a multiple of 16 and
-  // to a 16-byte-skewed stride (KS), plus a 32-row panel of dense logits.  Used when it all fits this launch's LDS.
-  constexpr bool kMfmaCfg = (G == 16) && (F % 32 == 0) && (F <= 128);  // F = 256 would spill (64 operand VGPRs)
-  constexpr int KS = F + 8;                       // bf16 elements per row of Khi / Klo
-  const int npad = (n + 15) & ~15;
-  const int PS = npad + 4;                        // floats per panel row
-  const int res_mfma = max(n * F, npad * KS);     // floats: Khi + Klo take npad*KS*2 bf16 each
-  const int cols_b = ((ne * (n <= 256 ? 1 : 2)) + 19) & ~15;
-  const size_t mfma_base = ((size_t)res_mfma + ((n + 3) & ~3) + ((n + 4) & ~3)) * 4 + kBlockScratchBytes + cols_b +
-                           (size_t)32 * PS * 4 + (size_t)32 * KS * 4;
-  const bool mfma_cfg_ok = kMfmaCfg && n <= 256;
-  // the per-edge array stays in LDS if the matrix-core layout still fits with it, else it goes to the global
-  // scratch (attn_edge in training, the caller's edge_ws in inference) -- that keeps ranges up to ~165 nodes
-  // (f = 128) on the matrix cores
-  const bool mfma_lw_lds = mfma_cfg_ok && !edge_global && mfma_base + (size_t)((ne + 3) & ~3) * 4 <= (size_t)lds_bytes;
-  const bool mfma_lw_glob = mfma_cfg_ok && !mfma_lw_lds && edge_ws != nullptr && mfma_base <= (size_t)lds_bytes;
-  const bool use_mfma = mfma_lw_lds || mfma_lw_glob;
-  const bool w_global = use_mfma ? mfma_lw_glob : edge_global;
-  const BlockLds L = carve_block_lds(lds, n, w_global ? 0 : ne, F, wave, use_mfma ? res_mfma : -1);
-  float *panel = reinterpret_cast<float *>(L.cols + cols_b);
-  __bf16 *qhi = reinterpret_cast<__bf16 *>(panel + (size_t)32 * PS), *qlo = qhi + (size_t)32 * KS;  // Q rows of a round
+  const bool w_global = edge_global;
+  const BlockLds L = carve_block_lds(lds, n, w_global ? 0 : ne, F, wave);
   // exp values between the passes: LDS, or (large ranges) this range's slice of the global scratch
   const EdgeArr W{w_global ? nullptr : L.lw, w_global ? edge_ws + (size_t)head * g.nnz + e0 : nullptr};
   int *sci = reinterpret_cast<int *>(L.sc);  // pass A stages columns only (first 256 B of the scratch)
@@ -73,159 +54,13 @@ __global__ __launch_bounds__(kBlockThreads) void gt_block_fwd_kernel(Csr g, cons
 
   DFGNN_STAMP(0)
   load_block_index(L, g, n0, n, e0, ne);
-  __bf16 *khi = reinterpret_cast<__bf16 *>(L.res), *klo = khi + (size_t)npad * KS;
-  if constexpr (kMfmaCfg) {
-    if (use_mfma) {
-      const float *Ksrc = K + (size_t)n0 * hf + (size_t)head * F;
-      constexpr int C8 = F / 8;
-      for (int idx = threadIdx.x; idx < npad * C8; idx += kBlockThreads) {
-        const int row = idx / C8, c8 = idx - row * C8;
-        float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
-        if (row < n) {
-          const float4 *src = reinterpret_cast<const float4 *>(Ksrc + (size_t)row * hf + 8 * c8);
-          a = src[0];
-          b = src[1];
-        }
-        bf16x8 hi, lo;
-        split_bf16x8(a, b, hi, lo);
-        *reinterpret_cast<bf16x8 *>(khi + (size_t)row * KS + 8 * c8) = hi;
-        *reinterpret_cast<bf16x8 *>(klo + (size_t)row * KS + 8 * c8) = lo;
-      }
-      // edge values go to LDS once (coalesced), so the per-round gather phase issues no global loads at all
-      if (g.val && !w_global)
-        for (int e = threadIdx.x; e < ne; e += kBlockThreads) L.lw[e] = g.val[e0 + e];
-    }
-  }
-  if (!use_mfma) load_resident(L.res, K + (size_t)n0 * hf + (size_t)head * F, n, F, hf);
+  load_resident(L.res, K + (size_t)n0 * hf + (size_t)head * F, n, F, hf);
   __syncthreads();
   DFGNN_STAMP(1)
 
   // ---- pass A: logits of every edge of the range, K served from LDS; then the row softmax ----------
-  if constexpr (kMfmaCfg) {
-    if (use_mfma) {
-      constexpr int NT = F / 32;                  // MFMA k-steps per tile
-      const int mi = lane & 15, mq = lane >> 4;   // MFMA lane coordinates: row/col within the tile, k-quarter
-      const int ntile = npad >> 4;
-      const int blk = wave >> 3;                  // which of the round's two 16-row blocks this wave multiplies
-      // The round's 32 Q rows are staged in LDS as bf16 halves by the whole workgroup (each element is loaded
-      // from HBM once, one float4 per thread, a round ahead); every wave then reads its A fragments from LDS.
-      constexpr int F4 = F / 4;
-      const int qrow = threadIdx.x / F4, qc4 = threadIdx.x % F4;
-      float4 qpre = make_float4(0.f, 0.f, 0.f, 0.f);
-      auto load_qpre = [&](int r0) {
-        qpre = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (qrow < 32 && r0 + qrow < n)
-          qpre = *reinterpret_cast<const float4 *>(Qh + (size_t)(n0 + r0 + qrow) * hf + 4 * qc4);
-      };
-      auto store_q = [&]() {
-        if (qrow < 32) {
-          typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
-          const float x[4] = {qpre.x, qpre.y, qpre.z, qpre.w};
-          bf16x4 h4, l4;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const __bf16 hh = (__bf16)x[j];
-            h4[j] = hh;
-            l4[j] = (__bf16)(x[j] - (float)hh);
-          }
-          *reinterpret_cast<bf16x4 *>(qhi + (size_t)qrow * KS + 4 * qc4) = h4;
-          *reinterpret_cast<bf16x4 *>(qlo + (size_t)qrow * KS + 4 * qc4) = l4;
-        }
-      };
-      load_qpre(0);
-      store_q();
-      load_qpre(32);
-      lds_barrier();
-#ifdef DFGNN_STAMPS
-      unsigned long long racc[6] = {0, 0, 0, 0, 0, 0};
-#endif
-      for (int r0 = 0; r0 < n; r0 += 32) {
-        DFGNN_RT(t0)
-        bf16x8 ah[NT], al[NT];
-        const size_t aoff = (size_t)(16 * blk + mi) * KS + 8 * mq;
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-          ah[t] = *reinterpret_cast<const bf16x8 *>(qhi + aoff + 32 * t);
-          al[t] = *reinterpret_cast<const bf16x8 *>(qlo + aoff + 32 * t);
-        }
-        DFGNN_RT(t1)
-        for (int tile = wave & 7; tile < ntile; tile += 8) {
-          f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-          const size_t boff = (size_t)(16 * tile + mi) * KS + 8 * mq;
-#pragma unroll
-          for (int t = 0; t < NT; ++t) {
-            const bf16x8 bh = *reinterpret_cast<const bf16x8 *>(khi + boff + 32 * t);
-            const bf16x8 bl = *reinterpret_cast<const bf16x8 *>(klo + boff + 32 * t);
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[t], bh, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[t], bl, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[t], bh, acc, 0, 0, 0);
-          }
-          float *pc = panel + (size_t)(16 * blk + 4 * mq) * PS + 16 * tile + mi;  // D: row 4*mq + reg, col mi
-          pc[0] = acc[0];
-          pc[PS] = acc[1];
-          pc[2 * PS] = acc[2];
-          pc[3 * PS] = acc[3];
-        }
-        DFGNN_RT(t2)
-        lds_barrier();
-        DFGNN_RT(t3)
-        // rows r0 .. r0+31: two per wave; logits are gathered from the panel, val (if any) waits in lw
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const int r = r0 + wave + u * kBlockWaves;
-          if (r >= n) continue;
-          const int lb = __builtin_amdgcn_readfirstlane(L.rp[r]);
-          const int deg = __builtin_amdgcn_readfirstlane(L.rp[r + 1]) - lb;
-          const float *prow = panel + (size_t)(r - r0) * PS;
-          if (deg <= kWave) {
-            float sv = -INFINITY;
-            if (lane < deg) {
-              sv = prow[block_col(L, narrow, lb + lane)];
-              if (g.val) sv *= w_global ? g.val[e0 + lb + lane] : L.lw[lb + lane];
-            }
-            const float mx = wave_max(sv);
-            const float pv = (sv == -INFINITY) ? 0.f : fast_exp(sv - mx);
-            const float sum = wave_sum(pv);
-            if (lane < deg) W.store(lb + lane, pv);
-            if (lane == 0) L.rinv[r] = (sum != 0.f) ? 1.f / sum : 0.f;
-          } else {
-            float mx = -INFINITY;
-            for (int e = lane; e < deg; e += kWave) {
-              float sv = prow[block_col(L, narrow, lb + e)];
-              if (g.val) sv *= w_global ? g.val[e0 + lb + e] : L.lw[lb + e];
-              W.store(lb + e, sv);
-              mx = fmaxf(mx, sv);
-            }
-            mx = wave_max(mx);
-            float sum = 0.f;
-            for (int e = lane; e < deg; e += kWave) {  // a lane re-reads only the slots it wrote itself
-              const float sv = W.load(lb + e);
-              const float pv = (sv == -INFINITY) ? 0.f : fast_exp(sv - mx);
-              W.store(lb + e, pv);
-              sum += pv;
-            }
-            sum = wave_sum(sum);
-            if (lane == 0) L.rinv[r] = (sum != 0.f) ? 1.f / sum : 0.f;
-          }
-        }
-        if (r0 + 32 < n) {
-          store_q();              // next round's Q rows (everyone finished reading this round's A fragments
-          load_qpre(r0 + 64);     //  before the first barrier of the round)
-        }
-        DFGNN_RT(t4)
-        lds_barrier();  // the panel is rewritten by the next round; the Q prefetch stays in flight
-        DFGNN_RT(t5)
-        DFGNN_RACC(0, t0, t1) DFGNN_RACC(1, t1, t2) DFGNN_RACC(2, t2, t3) DFGNN_RACC(3, t3, t4) DFGNN_RACC(4, t4, t5)
-        DFGNN_RACC(5, t0, t0 + 1)
-      }
-#ifdef DFGNN_STAMPS
-      if (threadIdx.x == 0 && dfgnn_round_stamps)
-        for (int k = 0; k < 6; ++k) dfgnn_round_stamps[((size_t)blockIdx.x * gridDim.y + blockIdx.y) * 8 + k] = racc[k];
-#endif
-    }
-  }
-  if (!use_mfma) {
-  Frag<C> q_next;
+  {
+    Frag<C> q_next;
     if (wave < n) frag_load_full<C>(q_next, Qh + (size_t)(n0 + wave) * hf, gl);
     for (int r = wave; r < n; r += kBlockWaves) {
       // block-relative edge range of row n0 + r (wave-uniform: keep the loop control in SGPRs)
@@ -335,7 +170,7 @@ int launch_gt_block_fwd(const Csr &g, const Plan &p, const float *Q, const float
   if (p.num_edge_global > 0 && !edge_ws) return kErrBadArg;
   const dim3 grid(p.num_fit - first, g.h);
   const int *fit = p.fit() + 2 * (size_t)first;
-  const size_t lds = kLdsBytes;  // one workgroup per CU either way; the matrix-core layout needs the headroom
+  const size_t lds = block_lds_bytes(p, g.f);
   return dispatch_vec4(g.f, [&](auto cfg) {
     using C = decltype(cfg);
     if (attn_edge) {

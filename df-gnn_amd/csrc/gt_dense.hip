@@ -4,7 +4,8 @@
 // with more than 128 nodes).  See dfgnn_dense.hpp for the numerics and the operand layouts.  These kernels replace,
 // for such ranges, the same reference kernels as gt_block.hip / gt_block_bwd.hip (fused_gtconv_hyper.cu:228-560,
 // fused_gtconv_backward.cu:40-191): the dot products, the softmax and the weighted sums of a whole member graph
-// are done as masked dense attention on v_mfma_f32_16x16x32_bf16.
+// are done as masked dense attention on v_mfma_f32_16x16x32_f16 (fp16 hi / lo operand halves under power-of-two
+// scales: fp32-equivalent, see dfgnn_dense.hpp).
 //
 // Forward:   S^T = K Q^T  ->  masked row softmax in registers  ->  O^T = V^T P^T
 //            The mask is a byte map [i][j] -> position of edge (i, j) in row i (0xFF: no edge), built once per
@@ -13,12 +14,12 @@
 //            dV^T = dO^T P first (dO image resident; the strips take their dO rows -- the register operand of the next
 //            product -- from it, so dO is read from global memory once), then
 //            dP^T = V dO^T ;  t_i = sum_j P_ij dP_ij ;  dS = P o (dP - t)        (registers)
-//            dQ^T = K^T dS^T ,  dK^T = Q^T dS                                    (P / dS through a bf16 tile in LDS)
+//            dQ^T = K^T dS^T ,  dK^T = Q^T dS                                    (P / dS through an fp16 tile in LDS)
 //            A row block of 128 rows keeps dP / P / dS of all (one or two) 128-column blocks in registers, so t_i
 //            needs no extra sweep and dQ accumulates in registers; dK / dV of a two-block range are accumulated
 //            across the row blocks by the lane that wrote them.
 // LDS: one feature image (K then V; dO, V, K, Q in turn; 72 KB) + the byte map (forward) or one 128 x 136-float
-// tile (backward: P as fp32, then P and dS as interleaved bf16 hi | lo rows, 68 KB).  The next image's global
+// tile (backward: P as fp32, then P and dS as interleaved fp16 hi | lo rows, 68 KB).  The next image's global
 // loads are issued one phase ahead into registers, so a phase change costs a barrier and an LDS store.  Every barrier
 // is lds_barrier() (s_waitcnt lgkmcnt(0); s_barrier): __syncthreads() would also wait for vmcnt(0), i.e. for the
 // image that was just prefetched -- no thread ever reads another thread's global writes in these kernels.
@@ -69,11 +70,12 @@ __device__ __forceinline__ void dense_fwd_body(float *lds, int lds_bytes, const 
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
   const int npad = (n + 31) & ~31, ntile = npad >> 4, nstrip = (n + 15) >> 4;
   const int MS = npad + 4;
-  __bf16 *ihi = reinterpret_cast<__bf16 *>(lds), *ilo = ihi + (size_t)CR * RS;
+  h16 *ihi = reinterpret_cast<h16 *>(lds), *ilo = ihi + (size_t)CR * RS;
   unsigned char *map = reinterpret_cast<unsigned char *>(ilo + (size_t)CR * RS);
   const int map_bytes = nstrip * 16 * MS;
   int *rp = reinterpret_cast<int *>(map + ((map_bytes + 15) & ~15));
-  float *acl = reinterpret_cast<float *>(rp + ((n + 4) & ~3));     // [npad] attn_col of the range (GAT only)
+  float *smax = reinterpret_cast<float *>(rp + ((n + 4) & ~3));    // [8] per-wave maxima of the image being staged
+  float *acl = smax + kDenseWaves;                                 // [npad] attn_col of the range (GAT only)
   float *pstage = acl + (GAT ? npad : 0);                          // [ne] normalised attention values, if it fits
   const size_t fixed_bytes = (size_t)(reinterpret_cast<char *>(pstage) - reinterpret_cast<char *>(lds));
   const bool stage_attn = WRITE_ATTN && fixed_bytes + (size_t)ne * 4 <= (size_t)lds_bytes;
@@ -156,19 +158,33 @@ __device__ __forceinline__ void dense_fwd_body(float *lds, int lds_bytes, const 
       else map[i * MS + j] = (unsigned char)(e - rp[i]);
     }
   }
-  dense_stage_store<F, CR>(st, ihi, ilo, fr);
-  bf16x8 qh[NS][KT], ql[NS][KT];
+  // The image's power-of-two scale needs the largest magnitude over the whole workgroup: one more barrier here (the
+  // later images post theirs ahead of a barrier that is there anyway).
+  wg_max_post(smax, dense_stage_absmax<F, CR>(st));
+  lds_barrier();
+  Pow2Scale isc = pow2_scale(wg_max_read(smax));  // scale of the resident image
+  dense_stage_store<F, CR>(st, ihi, ilo, isc.s, fr);
+  float kinv[NCH];    // 1 / scale of K chunk c ...
+  float qinv[NS];     // ... and of this wave's Q strips: S = acc * kinv * qinv
+  kinv[0] = isc.inv;
+  hx8 qh[NS][KT], ql[NS][KT];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) qinv[s] = 1.f;
   if constexpr (!GAT) {
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
       const LaneIds L = lane_ids();
       const bool valid = (wave + 8 * s) * 16 + L.mi < n;
+      float qm = 0.f;
 #pragma unroll
       for (int t = 0; t < KT; ++t) {
-        float4 a = qa[s][t], b = qb[s][t];
-        if (!valid || (FR < F && 32 * t + 8 * L.mq >= fr)) a = b = make_float4(0.f, 0.f, 0.f, 0.f);
-        split_bf16x8(a, b, qh[s][t], ql[s][t]);
+        if (!valid || (FR < F && 32 * t + 8 * L.mq >= fr)) qa[s][t] = qb[s][t] = make_float4(0.f, 0.f, 0.f, 0.f);
+        qm = fmaxf(qm, absmax8(qa[s][t], qb[s][t]));
       }
+      const Pow2Scale qs = pow2_scale(wave_max(qm));
+      qinv[s] = qs.inv;
+#pragma unroll
+      for (int t = 0; t < KT; ++t) split_hx8(qa[s][t], qb[s][t], qs.s, qh[s][t], ql[s][t]);
     }
   }
   lds_barrier();
@@ -197,8 +213,11 @@ __device__ __forceinline__ void dense_fwd_body(float *lds, int lds_bytes, const 
 #pragma unroll
   for (int c = 0; c < (GAT ? 0 : NCH); ++c) {
     if (c > 0) {
+      wg_max_post(smax, dense_stage_absmax<F, CR>(st));
       lds_barrier();
-      dense_stage_store<F, CR>(st, ihi, ilo, fr);
+      isc = pow2_scale(wg_max_read(smax));
+      kinv[c] = isc.inv;
+      dense_stage_store<F, CR>(st, ihi, ilo, isc.s, fr);
       dense_stage_load<F, CR>(st, Vb, hf, 0, n, fr);  // V rows 0.., for the first O^T chunk
       lds_barrier();
     }
@@ -237,7 +256,7 @@ __device__ __forceinline__ void dense_fwd_body(float *lds, int lds_bytes, const 
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const bool edge = ((w >> (8 * r)) & 0xFFu) != 0xFFu;
-          const float x = edge ? S[s][jt][r] : -INFINITY;
+          const float x = edge ? (GAT ? S[s][jt][r] : S[s][jt][r] * (kinv[jt / TPC] * qinv[s])) : -INFINITY;
           S[s][jt][r] = x;
           mx = fmaxf(mx, x);
         }
@@ -309,12 +328,24 @@ __device__ __forceinline__ void dense_fwd_body(float *lds, int lds_bytes, const 
   for (int s = 0; s < NS; ++s)
 #pragma unroll
     for (int ft = 0; ft < FT; ++ft) o[s][ft] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // P (the exp values, in [0, 1]) enters the product under the constant scale 2^14, V under its image's; the
+  // accumulators are kept in units of the current image's scale.
 #pragma unroll
   for (int c = 0; c < NCH; ++c) {
     if (!(GAT && c == 0)) {  // (GAT: X rows 0.. are the image already)
+      wg_max_post(smax, dense_stage_absmax<F, CR>(st));
       lds_barrier();       // every strip is done with the previous image
-      dense_stage_store<F, CR>(st, ihi, ilo, fr);
+      const float prev_inv = isc.inv;
+      isc = pow2_scale(wg_max_read(smax));
+      dense_stage_store<F, CR>(st, ihi, ilo, isc.s, fr);
       if (c + 1 < NCH) dense_stage_load<F, CR>(st, Vb, hf, (c + 1) * CR, n, fr);
+      if (c > 0) {  // accumulated under the previous chunk's scale
+        const float ratio = prev_inv * isc.s;
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+          for (int ft = 0; ft < FT; ++ft) o[s][ft] *= ratio;
+      }
       lds_barrier();
     }
     if (c == 0) { DFGNN_DSTAMP(4) }
@@ -325,7 +356,8 @@ __device__ __forceinline__ void dense_fwd_body(float *lds, int lds_bytes, const 
 #pragma unroll
         for (int u = 0; u < CR / 32; ++u) {
           const int jb = (CR / 32) * c + u;  // 32-column block of P
-          if (2 * jb < ntile) dense_cols_mma<F, (NS == 1 ? 8 : 4)>(o[s], ihi, ilo, u, S[s][2 * jb], S[s][2 * jb + 1], L);
+          if (2 * jb < ntile)
+            dense_cols_mma<F, (NS == 1 ? 8 : 4)>(o[s], ihi, ilo, u, S[s][2 * jb], S[s][2 * jb + 1], kUnitScale, L);
         }
       }
     }
@@ -334,7 +366,9 @@ __device__ __forceinline__ void dense_fwd_body(float *lds, int lds_bytes, const 
   for (int s = 0; s < NS; ++s) {
     const LaneIds L = lane_ids();
     const int i = (wave + 8 * s) * 16 + L.mi;
-    if (i < n) dense_store_acc<FT, (FR < F)>(o[s], inv[s], Ob, (unsigned)i * (unsigned)hf + 4u * L.mq, false, 4 * L.mq, fr);
+    if (i < n)
+      dense_store_acc<FT, (FR < F)>(o[s], inv[s] * (isc.inv * kUnitScaleInv), Ob, (unsigned)i * (unsigned)hf + 4u * L.mq, false,
+                                    4 * L.mq, fr);
   }
   DFGNN_DSTAMP(5)
   DFGNN_DSTAMP(6)
@@ -399,7 +433,7 @@ struct DenseBwdGeom {
   static constexpr int RB = (CW == kDenseWideRows) ? 80 : 128;  // rows per row block
   static constexpr int RBP = (RB + 31) & ~31;                  // ... padded to the 32-deep k-blocks of the products
   static constexpr int U = CW / 16;                            // 16-column tiles per column block
-  static constexpr int TS = CW + 8;                            // floats per tile row == 2 x TS bf16 (hi | lo)
+  static constexpr int TS = CW + 8;                            // floats per tile row == 2 x TS fp16 (hi | lo)
 };
 
 // GAT training backward (GAT = true; Q = attn_row [m, h], K = attn_col [m, h], V = X, dV = grad_feat; attn_edge, dQ, dK
@@ -426,13 +460,13 @@ __device__ __forceinline__ void dense_bwd_body(float *lds, const Csr &g, int n0,
   using D = DenseCfg<F>;
   using G = DenseBwdGeom<CW, NBLK>;
   constexpr int RS = D::RS, KT = D::KT, FT = D::FT, RB = G::RB, RBP = G::RBP, U = G::U, TS = G::TS;
-  constexpr int TB = 2 * TS;  // bf16 elements per interleaved tile row: hi at +0, lo at +TS
+  constexpr int TB = 2 * TS;  // fp16 elements per interleaved tile row: hi at +0, lo at +TS
   // edges fetched ahead per thread (GAT: each edge also carries its dropout random, so fewer fit the registers)
   constexpr int PRE = GAT ? 10 : kDensePre;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);  // = this wave's strip of a row block
-  __bf16 *ihi = reinterpret_cast<__bf16 *>(lds), *ilo = ihi + (size_t)CW * RS;
+  h16 *ihi = reinterpret_cast<h16 *>(lds), *ilo = ihi + (size_t)CW * RS;
   float *T = reinterpret_cast<float *>(ilo + (size_t)CW * RS);
-  __bf16 *Tb = reinterpret_cast<__bf16 *>(T);
+  h16 *Tb = reinterpret_cast<h16 *>(T);
   const size_t hf = (size_t)g.h * fr, hoff = (size_t)head * fr;
   const float *Qb = Q + (size_t)n0 * hf + hoff, *Kb = K + (size_t)n0 * hf + hoff, *Vb = V + (size_t)n0 * hf + hoff,
               *dOb = dO + (size_t)n0 * hf + hoff;
@@ -440,7 +474,8 @@ __device__ __forceinline__ void dense_bwd_body(float *lds, const Csr &g, int n0,
   const float *attn_h = attn_edge + (size_t)head * g.nnz;
   // GAT: per-node scalars of the range, [SN] each, behind the tile: attn_row, attn_col, edge_max, 1 / edge_sum
   constexpr int SN = NBLK * CW;
-  float *arl = T + RBP * TS, *acl = arl + SN, *mxl = acl + SN, *ivl = mxl + SN;
+  float *smax = T + RBP * TS;            // [8] per-wave maxima of the image being staged, [8] of the dS tile
+  float *arl = smax + 2 * kDenseWaves, *acl = arl + SN, *mxl = acl + SN, *ivl = mxl + SN;
   (void)arl, (void)acl, (void)mxl, (void)ivl;
 
   DFGNN_DSTAMP(0)
@@ -470,9 +505,17 @@ __device__ __forceinline__ void dense_bwd_body(float *lds, const Csr &g, int n0,
       dense_stage_load<F, CW>(st, src, hf, row0, row_end, fr);
     }
   };
-  auto image_commit = [&]() {
+  // An image goes to LDS in two steps around a barrier the phase structure has anyway: image_post() (with two column
+  // blocks: fetch it now) posts this wave's largest magnitude, image_store() -- after the barrier -- derives the
+  // image's power-of-two scale from all of them and stores the fp16 halves.  `isc` = scale of the resident image.
+  Pow2Scale isc{1.f, 1.f};
+  auto image_post = [&]() {
     if (NBLK > 1) dense_stage_load<F, CW>(st, next_src, hf, next_row0, next_end, fr);
-    dense_stage_store<F, CW>(st, ihi, ilo, fr);
+    wg_max_post(smax, dense_stage_absmax<F, CW>(st));
+  };
+  auto image_store = [&]() {
+    isc = pow2_scale(wg_max_read(smax));
+    dense_stage_store<F, CW>(st, ihi, ilo, isc.s, fr);
   };
   // Edges of a row block (CSR order, contiguous) are fetched several per thread at a time -- loads first, then the
   // scatter into the fp32 tile -- so that a batch costs one memory round trip; the first batch of a range is
@@ -497,25 +540,33 @@ __device__ __forceinline__ void dense_bwd_body(float *lds, const Csr &g, int n0,
     const float pp = fast_exp(leaky_relu(arl[i] + acl[j], ga.slope) - mxl[i]) * ivl[i];
     return (rnd > ga.drop.drop) ? pp : -pp;  // (no dropout: rnd = 1, drop = 0)
   };
-  // Zero the tile, scatter P of tile (i0, j0) into it (fp32; edges [ea, eb) are the rows of the row block) and, if
-  // `commit`, put the prefetched image into LDS.  `prefetched`: the first PRE edges per thread are in (pi, pj, pa).
-  auto load_tile = [&](int i0, int j0, int ea, int eb, bool prefetched, bool commit) {
+  // The P tile of (row block i0, column block j0), fp32: zero it, scatter the edges [ea, eb) of the row block into it
+  // and, if `commit`, put the prefetched image into LDS.  The first PRE edges per thread of a range's first tile were
+  // fetched in the prologue (pi, pj, pa) and are scattered ahead of the row-block loop (tile_open): used inside it they
+  // would be live -- and spilled -- around the whole loop.
+  auto tile_clear = [&]() {
     const int tid = opaque_tid();
     for (int k = tid; k < RBP * TS / 4; k += kDenseThreads)
       reinterpret_cast<float4 *>(T)[k] = make_float4(0.f, 0.f, 0.f, 0.f);
     lds_barrier();
-    if (prefetched) {
+  };
+  auto tile_open = [&](int ea, int eb) {  // first tile of the range: (i0, j0) = (0, 0)
+    tile_clear();
+    const int tid = opaque_tid();
 #pragma unroll
-      for (int k = 0; k < PRE; ++k) {
-        const int j = pj[k] - n0 - j0;
-        if (tid + k * kDenseThreads < eb - ea && j >= 0 && j < CW) {
-          if constexpr (GAT) T[(pi[k] - n0 - i0) * TS + j] = gat_p(pi[k] - n0, pj[k] - n0, pa[k]);
-          else T[(pi[k] - n0 - i0) * TS + j] = pa[k];
-        }
+    for (int k = 0; k < PRE; ++k) {
+      const int j = pj[k] - n0;
+      if (tid + k * kDenseThreads < eb - ea && j < CW) {
+        if constexpr (GAT) T[(pi[k] - n0) * TS + j] = gat_p(pi[k] - n0, pj[k] - n0, pa[k]);
+        else T[(pi[k] - n0) * TS + j] = pa[k];
       }
     }
+  };
+  auto load_tile = [&](int i0, int j0, int ea, int eb, bool opened, bool commit) {
+    const int tid = opaque_tid();
+    if (!opened) tile_clear();
     constexpr int B = 8;
-    for (int base = prefetched ? PRE * kDenseThreads : 0; base < eb - ea; base += B * kDenseThreads) {
+    for (int base = opened ? PRE * kDenseThreads : 0; base < eb - ea; base += B * kDenseThreads) {
       int bi[B], bj[B];
       float ba[B];
 #pragma unroll
@@ -535,29 +586,34 @@ __device__ __forceinline__ void dense_bwd_body(float *lds, const Csr &g, int n0,
         }
       }
     }
-    if (commit) image_commit();  // after the scatter: the edge loads were issued before the image's
+    if (commit) {  // after the scatter: the edge loads were issued before the image's
+      image_post();
+      lds_barrier();
+      image_store();
+    }
     lds_barrier();
   };
-  // this strip's 16 x CW values -> its own rows of the tile, as interleaved bf16 hi | lo halves
-  auto strip_to_tile = [&](const f32x4 (&X)[U]) {
+  // this strip's 16 x CW values (times the tile's power-of-two scale) -> its own rows of the tile, as interleaved fp16
+  // hi | lo halves
+  auto strip_to_tile = [&](const f32x4 (&X)[U], float tscale) {
     const LaneIds L = lane_ids();
-    __bf16 *trow = Tb + (wave * 16 + L.mi) * TB + 4 * L.mq;
+    h16 *trow = Tb + (wave * 16 + L.mi) * TB + 4 * L.mq;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      bf16x4 h4, l4;
+      hx4 h4, l4;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const __bf16 h = (__bf16)X[u][r];
+        const h16 h = (h16)(X[u][r] * tscale);
         h4[r] = h;
-        l4[r] = (__bf16)(X[u][r] - (float)h);
+        l4[r] = (h16)fmaf(X[u][r], tscale, -(float)h);
       }
-      *reinterpret_cast<bf16x4 *>(trow + 16 * u) = h4;
-      *reinterpret_cast<bf16x4 *>(trow + TS + 16 * u) = l4;
+      *reinterpret_cast<hx4 *>(trow + 16 * u) = h4;
+      *reinterpret_cast<hx4 *>(trow + TS + 16 * u) = l4;
     }
   };
-  // out^T[f][c] = sum_i X[i][f] Y[i][c]: X = the image (ni rows), Y = the bf16 tile, c = the 16 columns of column
-  // strip cs (rows j0 + 16 cs .. of the output)
-  auto column_strip = [&](float *outb, int j0, int cs, int ni, bool accumulate) {
+  // out^T[f][c] = sum_i X[i][f] Y[i][c]: X = the image (ni rows), Y = the fp16 tile, c = the 16 columns of column
+  // strip cs (rows j0 + 16 cs .. of the output); oscale = 1 / (image scale x tile scale)
+  auto column_strip = [&](float *outb, int j0, int cs, int ni, bool accumulate, float oscale) {
     const LaneIds L = lane_ids();
     const int j = j0 + cs * 16 + L.mi;
     f32x4 acc[FT];
@@ -567,16 +623,16 @@ __device__ __forceinline__ void dense_bwd_body(float *lds, const Csr &g, int n0,
     for (int ib = 0; ib < RBP / 32; ++ib) {
       if (32 * ib < ni) {
         const int yoff = (32 * ib + 4 * L.mq + L.tq) * TB + 16 * cs + 4 * L.tp;
-        const bf16x8 yh = dense_tr_pair(Tb + yoff, 16 * TB);
-        const bf16x8 yl = dense_tr_pair(Tb + yoff + TS, 16 * TB);
+        const hx8 yh = dense_tr_pair(Tb + yoff, 16 * TB);
+        const hx8 yl = dense_tr_pair(Tb + yoff + TS, 16 * TB);
         dense_kblock_mma<F, (NBLK == 1 ? 8 : 4)>(acc, ihi, ilo, (32 * ib + 4 * L.mq + L.tq) * RS + 4 * L.tp, 16 * RS, yh, yl);
       }
     }
-    if (j < n) dense_store_acc<FT, (FR < F)>(acc, 1.f, outb, (unsigned)j * (unsigned)hf + 4u * L.mq, accumulate, 4 * L.mq, fr);
+    if (j < n) dense_store_acc<FT, (FR < F)>(acc, oscale, outb, (unsigned)j * (unsigned)hf + 4u * L.mq, accumulate, 4 * L.mq, fr);
   };
   // one 16 x 16 output tile (column strip cs, feature tile ft): the unit of work for the strips past the eighth,
   // which are dealt out tile by tile so that all waves share them
-  auto column_tile = [&](float *outb, int j0, int cs, int ft, int ni, bool accumulate) {
+  auto column_tile = [&](float *outb, int j0, int cs, int ft, int ni, bool accumulate, float oscale) {
     const LaneIds L = lane_ids();
     const int j = j0 + cs * 16 + L.mi;
     f32x4 acc[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
@@ -584,32 +640,35 @@ __device__ __forceinline__ void dense_bwd_body(float *lds, const Csr &g, int n0,
     for (int ib = 0; ib < RBP / 32; ++ib) {
       if (32 * ib < ni) {
         const int yoff = (32 * ib + 4 * L.mq + L.tq) * TB + 16 * cs + 4 * L.tp;
-        const bf16x8 yh = dense_tr_pair(Tb + yoff, 16 * TB);
-        const bf16x8 yl = dense_tr_pair(Tb + yoff + TS, 16 * TB);
+        const hx8 yh = dense_tr_pair(Tb + yoff, 16 * TB);
+        const hx8 yl = dense_tr_pair(Tb + yoff + TS, 16 * TB);
         const int xoff = (32 * ib + 4 * L.mq + L.tq) * RS + 4 * L.tp + 16 * ft;
-        const bf16x8 xh = dense_tr_pair(ihi + xoff, 16 * RS);
-        const bf16x8 xl = dense_tr_pair(ilo + xoff, 16 * RS);
-        acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, yh, acc[0], 0, 0, 0);
-        acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xl, yh, acc[0], 0, 0, 0);
-        acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, yl, acc[0], 0, 0, 0);
+        const hx8 xh = dense_tr_pair(ihi + xoff, 16 * RS);
+        const hx8 xl = dense_tr_pair(ilo + xoff, 16 * RS);
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh, yh, acc[0], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xl, yh, acc[0], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh, yl, acc[0], 0, 0, 0);
       }
     }
     if (j < n)
-      dense_store_acc<1, (FR < F)>(acc, 1.f, outb, (unsigned)j * (unsigned)hf + 16u * ft + 4u * L.mq, accumulate, 16 * ft + 4 * L.mq, fr);
+      dense_store_acc<1, (FR < F)>(acc, oscale, outb, (unsigned)j * (unsigned)hf + 16u * ft + 4u * L.mq, accumulate, 16 * ft + 4 * L.mq, fr);
   };
-  auto column_phase = [&](float *outb, int j0, int ni, bool accumulate) {
+  auto column_phase = [&](float *outb, int j0, int ni, bool accumulate, float oscale) {
     const int nstrips = min(U, (n - j0 + 15) >> 4);
-    if (wave < nstrips) column_strip(outb, j0, wave, ni, accumulate);
+    if (wave < nstrips) column_strip(outb, j0, wave, ni, accumulate, oscale);
     if (U > kDenseWaves)
       for (int unit = wave; unit < (nstrips - kDenseWaves) * FT; unit += kDenseWaves)
-        column_tile(outb, j0, kDenseWaves + unit / FT, unit % FT, ni, accumulate);
+        column_tile(outb, j0, kDenseWaves + unit / FT, unit % FT, ni, accumulate, oscale);
   };
 
   int ea = e0, eb = (RB < n) ? g.row_ptr[n0 + RB] : e0 + ne;  // edges of the current row block
   edges_prefetch(ea, eb);
   image_prefetch(dOb, 0, min(n, RB));
+  tile_open(ea, eb);
   float gcol = 0.f;  // GAT: grad_attn_col of column opaque_tid(), accumulated over the row blocks
-  for (int i0 = 0; i0 < n; i0 += RB) {
+  constexpr int NRB = (NBLK * CW + RB - 1) / RB;  // row blocks at most (one for a single tile: then this is no loop)
+  for (int rb = 0; rb < NRB && rb * RB < n; ++rb) {
+    const int i0 = rb * RB;
     const int ni = min(n - i0, RB);
     const bool row_wave = wave * 16 < ni;
     const bool first = i0 == 0;
@@ -617,11 +676,13 @@ __device__ __forceinline__ void dense_bwd_body(float *lds, const Csr &g, int n0,
     // ---- dV^T = dO^T P, column block by column block; the strips pick up their dO rows (the register operand of
     //      dP) and their P values on the way: dO is read from global memory once ---------------------------------------
     f32x4 dS[NBLK][U], Pr[NBLK][U];
-    bf16x8 gh[KT], gl[KT];
+    hx8 gh[KT], gl[KT];
+    float doinv = 1.f;  // 1 / scale of this row block's dO image (and of gh / gl, which are read from it)
 #pragma unroll
     for (int jc = 0; jc < NBLK; ++jc) {
       const int j0 = jc * CW;
       load_tile(i0, j0, ea, eb, first && jc == 0, jc == 0);  // tile = P (fp32); image = dO rows of this row block
+      if (jc == 0) doinv = isc.inv;
       DFGNN_DSTAMP(9)
       if (jc + 1 == NBLK) image_prefetch(Vb, 0, n);  // next image: V rows 0..
       if (row_wave) {
@@ -630,8 +691,8 @@ __device__ __forceinline__ void dense_bwd_body(float *lds, const Csr &g, int n0,
           const int off = (wave * 16 + L.mi) * RS + 8 * L.mq;
 #pragma unroll
           for (int t = 0; t < KT; ++t) {
-            gh[t] = *reinterpret_cast<const bf16x8 *>(ihi + off + 32 * t);
-            gl[t] = *reinterpret_cast<const bf16x8 *>(ilo + off + 32 * t);
+            gh[t] = *reinterpret_cast<const hx8 *>(ihi + off + 32 * t);
+            gl[t] = *reinterpret_cast<const hx8 *>(ilo + off + 32 * t);
           }
         }
         const int nj = n - j0;
@@ -649,30 +710,33 @@ __device__ __forceinline__ void dense_bwd_body(float *lds, const Csr &g, int n0,
 #pragma unroll
           for (int u = 0; u < U; ++u)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) Pd[u][r] = Pr[jc][u][r] > 0.f ? Pr[jc][u][r] * ga.drop.scale : 0.f;
-          strip_to_tile(Pd);
+            for (int r = 0; r < 4; ++r) Pd[u][r] = Pr[jc][u][r] > 0.f ? Pr[jc][u][r] : 0.f;  // (x drop.scale at the store)
+          strip_to_tile(Pd, kUnitScale);
         } else {
-          strip_to_tile(Pr[jc]);  // in place, own rows only
+          strip_to_tile(Pr[jc], kUnitScale);  // in place, own rows only; P lies in [0, 1]
         }
       } else {  // (defined on every path: otherwise the arrays are carried around the row-block loop in registers)
 #pragma unroll
         for (int u = 0; u < U; ++u) Pr[jc][u] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (jc == 0) {
 #pragma unroll
-          for (int t = 0; t < KT; ++t) gh[t] = gl[t] = bf16x8{};
+          for (int t = 0; t < KT; ++t) gh[t] = gl[t] = hx8{};
         }
       }
       lds_barrier();
       DFGNN_DSTAMP(3)
-      column_phase(dVb, j0, ni, !first);
+      column_phase(dVb, j0, ni, !first, doinv * kUnitScaleInv * (GAT ? ga.drop.scale : 1.f));
+      if (jc + 1 == NBLK) image_post();  // V rows 0..
       lds_barrier();  // tile free (and, after the last block, the dO image)
     }
     DFGNN_DSTAMP(4)
 
     // ---- dP^T = V dO^T for every column block, t, dS ---------------------------------------------------------------
+    float dpinv[NBLK];  // dP = acc x 1 / (V image scale x dO scale)
 #pragma unroll
     for (int jc = 0; jc < NBLK; ++jc) {
-      image_commit();  // V rows of column block jc
+      image_store();  // V rows of column block jc
+      dpinv[jc] = isc.inv * doinv;
       if (jc + 1 < NBLK) {
         image_prefetch(Vb, (jc + 1) * CW, n);
       } else if constexpr (!GAT) {
@@ -681,7 +745,7 @@ __device__ __forceinline__ void dense_bwd_body(float *lds, const Csr &g, int n0,
         // GAT: the next row block's dO rows are all that is left to fetch (its edges are fetched after dS: they would
         // not fit next to dP / P).  Unconditional -- after the last row block it re-reads one row (unused): a prefetch
         // under a condition turns the staging registers into loop-carried values and spills them.
-        const bool more = i0 + RB < n;  // (last block: every load is clamped onto row i0 -- cache hits, no HBM traffic)
+        const bool more = rb + 1 < NRB && i0 + RB < n;  // (last block: every load is clamped onto row i0 -- cache hits, no HBM traffic)
         image_prefetch(dOb, more ? i0 + RB : i0, more ? min(n, i0 + 2 * RB) : i0 + 1);
       }
       lds_barrier();
@@ -699,9 +763,13 @@ __device__ __forceinline__ void dense_bwd_body(float *lds, const Csr &g, int n0,
 #pragma unroll
         for (int u = 0; u < U; ++u) dS[jc][u] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
-      lds_barrier();  // the next image overwrites this one
+      if (jc + 1 < NBLK) {
+        image_post();   // V rows of the next column block
+        lds_barrier();  // the next image overwrites this one
+      }
     }
     DFGNN_DSTAMP(1)
+    float tmax = 0.f;  // largest |dS| of this strip
     if (row_wave) {
       if constexpr (GAT) {  // g = keep dP / (1 - drop); P = |tile value|
 #pragma unroll
@@ -710,9 +778,14 @@ __device__ __forceinline__ void dense_bwd_body(float *lds, const Csr &g, int n0,
           for (int u = 0; u < U; ++u)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              dS[jc][u][r] = Pr[jc][u][r] > 0.f ? dS[jc][u][r] * ga.drop.scale : 0.f;
+              dS[jc][u][r] = Pr[jc][u][r] > 0.f ? dS[jc][u][r] * (dpinv[jc] * ga.drop.scale) : 0.f;
               Pr[jc][u][r] = fabsf(Pr[jc][u][r]);
             }
+      } else {
+#pragma unroll
+        for (int jc = 0; jc < NBLK; ++jc)
+#pragma unroll
+          for (int u = 0; u < U; ++u) dS[jc][u] *= dpinv[jc];
       }
       float t = 0.f;
 #pragma unroll
@@ -727,14 +800,22 @@ __device__ __forceinline__ void dense_bwd_body(float *lds, const Csr &g, int n0,
 #pragma unroll
         for (int u = 0; u < U; ++u)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) dS[jc][u][r] = Pr[jc][u][r] * (dS[jc][u][r] - t);
+          for (int r = 0; r < 4; ++r) {
+            dS[jc][u][r] = Pr[jc][u][r] * (dS[jc][u][r] - t);
+            tmax = fmaxf(tmax, fabsf(dS[jc][u][r]));
+          }
     }
+    if constexpr (!GAT) {
+      wg_max_post(smax + kDenseWaves, tmax);  // the dS tile's scale needs the largest |dS| of the row block
+      image_post();                           // K rows 0..
+    }
+    lds_barrier();  // the V image is free (and the two maxima are posted)
     DFGNN_DSTAMP(2)
 
     if constexpr (GAT) {
       // ---- G = dS LeakyReLU'(pre): row sums -> grad_attn_row, per-strip column sums -> the tile -> grad_attn_col -------
       float *cpart = T;  // [kDenseWaves][SN]
-      if (i0 + RB < n) {
+      if (rb + 1 < NRB && i0 + RB < n) {
         ea = eb;
         eb = (i0 + 2 * RB < n) ? g.row_ptr[n0 + i0 + 2 * RB] : e0 + ne;
       }
@@ -768,54 +849,64 @@ __device__ __forceinline__ void dense_bwd_body(float *lds, const Csr &g, int n0,
         if (tid < SN)
           for (int w = 0; w * 16 < ni; ++w) gcol += cpart[w * SN + tid];
       }
-      if constexpr (NBLK == 1 && CW > RB) edges_prefetch(ea, eb);  // (clamped loads: harmless after the last block)
       lds_barrier();  // the next row block zeroes the tile
       continue;
     }
 
     // ---- dQ^T = K^T dS^T (accumulated over the column blocks in registers) and dK^T = Q^T dS ---------------------------
-    f32x4 qacc[FT];
+    f32x4 qacc[FT];  // in units of 1 / (dS tile scale x current K image scale)
 #pragma unroll
     for (int ft = 0; ft < FT; ++ft) qacc[ft] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const Pow2Scale ts = pow2_scale(wg_max_read(smax + kDenseWaves));  // scale of the dS tile(s) of this row block
+    float kinv = 1.f;  // 1 / scale of the K block qacc is accumulated under
 #pragma unroll
     for (int jc = 0; jc < NBLK; ++jc) {
       const int j0 = jc * CW, nj = min(n - j0, CW);
-      if (row_wave) strip_to_tile(dS[jc]);
-      image_commit();                       // K rows j0..
+      if (row_wave) strip_to_tile(dS[jc], ts.s);
+      image_store();                        // K rows j0..
+      if (jc > 0) {                         // accumulated under the previous K block's scale
+        const float ratio = kinv * isc.s;
+#pragma unroll
+        for (int ft = 0; ft < FT; ++ft) qacc[ft] *= ratio;
+      }
+      kinv = isc.inv;
       image_prefetch(Qb, i0, i0 + ni);      // next image: Q rows of this row block
       lds_barrier();
       DFGNN_DSTAMP(5)
       if (row_wave) {
         const LaneIds L = lane_ids();
-        const __bf16 *srow = Tb + (wave * 16 + L.mi) * TB + 8 * L.mq;
+        const h16 *srow = Tb + (wave * 16 + L.mi) * TB + 8 * L.mq;
 #pragma unroll
         for (int jb = 0; jb < CW / 32; ++jb) {
           if (32 * jb < nj) {
             // natural k order: element t of lane (mi, mq) is column 32 jb + 8 mq + t of dS / that row of K
-            const bf16x8 sh = *reinterpret_cast<const bf16x8 *>(srow + 32 * jb);
-            const bf16x8 sl = *reinterpret_cast<const bf16x8 *>(srow + TS + 32 * jb);
+            const hx8 sh = *reinterpret_cast<const hx8 *>(srow + 32 * jb);
+            const hx8 sl = *reinterpret_cast<const hx8 *>(srow + TS + 32 * jb);
             dense_kblock_mma<F, (NBLK == 1 ? 8 : 4)>(qacc, ihi, ilo, (32 * jb + 8 * L.mq + L.tq) * RS + 4 * L.tp, 4 * RS, sh, sl);
           }
         }
         if (jc + 1 == NBLK) {  // dQ rows of this row block are complete: store them now, under the dK product
           const int i = i0 + wave * 16 + L.mi;
-          if (i < i0 + ni) dense_store_acc<FT, (FR < F)>(qacc, 1.f, dQb, (unsigned)i * (unsigned)hf + 4u * L.mq, false, 4 * L.mq, fr);
+          if (i < i0 + ni)
+            dense_store_acc<FT, (FR < F)>(qacc, kinv * ts.inv, dQb, (unsigned)i * (unsigned)hf + 4u * L.mq, false, 4 * L.mq, fr);
         }
       }
       DFGNN_DSTAMP(6)
-      lds_barrier();  // K image free
-      image_commit();   // Q rows of this row block
+      image_post();     // Q rows of this row block
+      lds_barrier();    // K image free
+      image_store();
+      const float dkscale = isc.inv * ts.inv;
       if (jc + 1 < NBLK) {
         image_prefetch(Kb, (jc + 1) * CW, n);
-      } else if (i0 + RB < n) {  // the next row block starts with its edges and its dO rows
+      } else if (rb + 1 < NRB && i0 + RB < n) {  // the next row block starts with its edges and its dO rows
         ea = eb;
         eb = (i0 + 2 * RB < n) ? g.row_ptr[n0 + i0 + 2 * RB] : e0 + ne;
-        if (NBLK == 1) edges_prefetch(ea, eb);
         image_prefetch(dOb, i0 + RB, min(n, i0 + 2 * RB));
       }
       lds_barrier();
       DFGNN_DSTAMP(7)
-      column_phase(dKb, j0, ni, !first);
+      column_phase(dKb, j0, ni, !first, dkscale);
+      if (jc + 1 < NBLK) image_post();  // K rows of the next column block
       lds_barrier();  // Q image and dS tile free
     }
     DFGNN_DSTAMP(8)

@@ -36,12 +36,37 @@ SIGNATURES = {
 _lib = None
 
 
+def source_hash():
+    """sha256 (16 hex digits) over the library's sources in the Makefile's order; equals dfgnn_build_id() of a library
+    built from exactly these files."""
+    import hashlib
+    import re
+    mk = open(os.path.join(CSRC, "Makefile")).read()
+    names = []
+    for var in ("SRCS", "HDRS"):
+        names += re.search(rf"^{var}\s*:=\s*(.*)$", mk, flags=re.M).group(1).split()
+    h = hashlib.sha256()
+    for n in names + ["Makefile"]:
+        h.update(open(os.path.join(CSRC, n), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def build_id(path=LIB_PATH):
+    """dfgnn_build_id() of a built library (plain ctypes: no torch, no GPU)."""
+    L = ctypes.CDLL(path)
+    L.dfgnn_build_id.restype = ctypes.c_char_p
+    return L.dfgnn_build_id().decode()
+
+
 def build(force=False, jobs=8):
-    """Compile libdfgnn.so for gfx950 with hipcc (recipe: csrc/Makefile)."""
+    """Compile libdfgnn.so for gfx950 with hipcc (recipe: csrc/Makefile; incremental).  Raises if the result does not
+    carry the hash of the sources on disk (a stale library whose ABI number still matches)."""
     cmd = ["make", "-C", CSRC, "-j", str(jobs)]
     if force:
         cmd.append("-B")
     subprocess.check_call(cmd, stdout=subprocess.DEVNULL)
+    if build_id() != source_hash():
+        raise RuntimeError(f"{LIB_PATH} is stale: built from sources {build_id()}, on disk {source_hash()}")
     return LIB_PATH
 
 
@@ -65,6 +90,7 @@ def lib():
         L.dfgnn_error_string.argtypes = [ctypes.c_int]
         L.dfgnn_error_string.restype = ctypes.c_char_p
         L.dfgnn_abi_version.restype = ctypes.c_int
+        L.dfgnn_build_id.restype = ctypes.c_char_p
         L.dfgnn_plan_ints.argtypes = [ctypes.c_int]
         L.dfgnn_plan_ints.restype = ctypes.c_size_t
         L.dfgnn_preprocess_ws_bytes.argtypes = [ctypes.c_int, ctypes.c_int]

@@ -42,6 +42,9 @@ typedef void *dfgnn_stream_t; /* hipStream_t */
 
 int dfgnn_abi_version(void);
 const char *dfgnn_error_string(int code);
+/* 16 hex digits: sha256 of the library's sources (csrc Makefile list, in that order) at build time -- lets a
+ * caller detect a stale libdfgnn.so whose ABI number still matches. */
+const char *dfgnn_build_id(void);
 
 /* ---- block plan (optional, MI355X-specific; no counterpart in the reference) --------------------
  * A batch of small graphs (DGL GraphDataLoader, DFGNN/script/test/test_batch_graph.py:67-71) is a
@@ -54,8 +57,9 @@ const char *dfgnn_error_string(int code);
  * (it belongs to preprocessing, like the reference's preprocess_Hyper, DFGNN/layers/util.py:82-100).
  * Ranges that are dense (>= 1 edge per 32 node pairs), have at most 255 nodes, f in {8, 16, 32, 64, 128} and no
  * duplicate edges are additionally marked for the matrix-core kernels, which the GT
- * forward / backward use for them when val == NULL (unit edge values): masked dense attention on MFMA,
- * split-bf16 operands with fp32 accumulation (~2^-16 relative error per product).
+ * forward / backward use for them when val == NULL (unit edge values): masked dense attention on MFMA with
+ * fp32-equivalent arithmetic (operands as fp16 hi + lo halves under power-of-two scales, fp32 accumulation:
+ * ~3 x 2^-24 relative error per product, that of an fp32 FMA chain).
  *   plan       device buffer of dfgnn_plan_ints(m) int32
  *   meta_host  host buffer of 12 int32 filled on return: num_fit, num_spill, max_fit_nodes,
  *              max_fit_edges, m, nnz, f, lds_budget, num_edge_global, num_dense, 0, 0

@@ -24,8 +24,8 @@ def test_header_symbols_exported():
 
 def test_loader_signatures_cover_header():
     import dfgnn_native
-    compute = [n for n in _declared() if n not in ("dfgnn_abi_version", "dfgnn_error_string", "dfgnn_plan_ints",
-                                                       "dfgnn_preprocess_ws_bytes")]
+    compute = [n for n in _declared() if n not in ("dfgnn_abi_version", "dfgnn_error_string", "dfgnn_build_id",
+                                                       "dfgnn_plan_ints", "dfgnn_preprocess_ws_bytes")]
     assert sorted(dfgnn_native.SIGNATURES) == compute
     lib = dfgnn_native.lib()
     assert lib.dfgnn_abi_version() == 6
@@ -43,3 +43,10 @@ def test_header_arity_matches_loader():
         m = re.search(r"\bint\s+" + name + r"\s*\((.*?)\)\s*;", text, flags=re.S)
         assert m, name
         assert len([a for a in m.group(1).split(",") if a.strip()]) == len(argtypes), name
+
+
+def test_library_is_built_from_the_sources_on_disk():
+    """dfgnn_build_id() (sha256 of the sources, baked in at build time) equals the hash of csrc/ as it is now: a stale
+    libdfgnn.so cannot pass for a fresh one just because its ABI number matches."""
+    import dfgnn_native
+    assert dfgnn_native.build_id() == dfgnn_native.source_hash()

@@ -186,7 +186,7 @@ def test_synthetic_datasets_and_loader():
 
 def test_check_correct_follows_the_reference_rule(capsys):
     """isclose(rtol=1e-3) per element, a row with exactly one miss passes, every failing row is examined
-    (DFGNN/utils/util.py:211-236 of the reference); a relative-only miss inside the 1e-3 bar says so."""
+    (DFGNN/utils/util.py:211-236 of the reference); the check is relative only (atol 1e-8)."""
     a = torch.randn(6, 8)
     b = a.clone()
     assert check_correct(a, b)
@@ -202,4 +202,4 @@ def test_check_correct_follows_the_reference_rule(capsys):
     d[2, 1] = 3e-6
     d[2, 2] = -2e-6                                  # near-zero elements: relative check trips, absolute error tiny
     assert not check_correct(c, d)
-    assert "inside the 1e-3 parity bar" in capsys.readouterr().out
+    assert "error node 2 mismatch" in capsys.readouterr().out
