@@ -307,6 +307,36 @@ __device__ __forceinline__ void dense_store_acc(const f32x4 (&acc)[NFT], float s
   }
 }
 
+// accumulator tiles of one 16-row strip -> global rows, in WHOLE 128-byte lines: a tile gives a row 64 contiguous bytes
+// (4 lanes x float4), so storing tile by tile makes every store instruction write 16 half lines -- and a stream of
+// half-line writes costs the whole kernel ~15 % of the HBM rate it can reach (tools/diag/stream_probe.hip).  Here two
+// neighbouring tiles are stored together: lanes with mi < 8 take tile 2k of their own row, lanes with mi >= 8 take tile
+// 2k + 1 of row mi - 8 (one row_ror:8 DPP move per register), so the first instruction writes rows 0..7 of the strip
+// and the second rows 8..15, 128 contiguous bytes per row.  Must be called by all lanes of the wave; `row` = this
+// lane's row of the matrix (strip * 16 + mi), rows >= n are not stored.  NFT even; feature f of tile t = 16 t + 4 mq.
+constexpr int kDppRowRor8 = 0x128;
+template <int NFT>
+__device__ __forceinline__ void dense_store_rows(const f32x4 (&acc)[NFT], float scale, float *__restrict__ base, unsigned hf,
+                                                 int row, int n, const LaneIds &L) {
+  static_assert(NFT % 2 == 0, "tiles are stored in pairs");
+  const bool low = L.mi < 8;
+  const int prow = low ? row + 8 : row - 8;  // the partner lane's row
+  const int r1 = low ? row : prow, r2 = low ? prow : row;
+  const unsigned o1 = (unsigned)r1 * hf + (low ? 0u : 16u) + 4u * L.mq, o2 = (unsigned)r2 * hf + (low ? 16u : 0u) + 4u * L.mq;
+#pragma unroll
+  for (int k = 0; k < NFT / 2; ++k) {
+    float4 a, b;
+    a.x = acc[2 * k][0] * scale; a.y = acc[2 * k][1] * scale; a.z = acc[2 * k][2] * scale; a.w = acc[2 * k][3] * scale;
+    b.x = dpp_perm<kDppRowRor8>(acc[2 * k + 1][0] * scale);
+    b.y = dpp_perm<kDppRowRor8>(acc[2 * k + 1][1] * scale);
+    b.z = dpp_perm<kDppRowRor8>(acc[2 * k + 1][2] * scale);
+    b.w = dpp_perm<kDppRowRor8>(acc[2 * k + 1][3] * scale);
+    const float4 v1 = low ? a : b, v2 = low ? b : a;
+    if (r1 < n) st32_f4(base, o1 + 32 * k, v1);
+    if (r2 < n) st32_f4(base, o2 + 32 * k, v2);
+  }
+}
+
 __device__ __forceinline__ float xor16_32_max(float v) {
   v = fmaxf(v, __shfl_xor(v, 16));
   return fmaxf(v, __shfl_xor(v, 32));

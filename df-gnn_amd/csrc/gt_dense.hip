@@ -39,6 +39,16 @@ __device__ unsigned long long *dfgnn_dense_stamps = nullptr;  // [wg][16] phase 
 #define DFGNN_DSTAMP(k)
 #endif
 
+}  // namespace dfgnn
+#ifndef DFGNN_FW128
+#define DFGNN_FW128 128
+#endif
+#ifndef DFGNN_RING160
+#define DFGNN_RING160 2  // prefetch distance (image phases) of the 129..160-node backward
+#endif
+#include "dfgnn_dense_wide.hpp"
+namespace dfgnn {
+
 // =====================================================================================================================
 // forward
 // =====================================================================================================================
@@ -366,9 +376,12 @@ __device__ __forceinline__ void dense_fwd_body(float *lds, int lds_bytes, const 
   for (int s = 0; s < NS; ++s) {
     const LaneIds L = lane_ids();
     const int i = (wave + 8 * s) * 16 + L.mi;
-    if (i < n)
-      dense_store_acc<FT, (FR < F)>(o[s], inv[s] * (isc.inv * kUnitScaleInv), Ob, (unsigned)i * (unsigned)hf + 4u * L.mq, false,
-                                    4 * L.mq, fr);
+    if constexpr (FR == F) {
+      if ((wave + 8 * s) * 16 < n) dense_store_rows<FT>(o[s], inv[s] * (isc.inv * kUnitScaleInv), Ob, (unsigned)hf, i, n, L);
+    } else if (i < n) {
+      dense_store_acc<FT, true>(o[s], inv[s] * (isc.inv * kUnitScaleInv), Ob, (unsigned)i * (unsigned)hf + 4u * L.mq, false,
+                                4 * L.mq, fr);
+    }
   }
   DFGNN_DSTAMP(5)
   DFGNN_DSTAMP(6)
@@ -626,6 +639,12 @@ __device__ __forceinline__ void dense_bwd_body(float *lds, const Csr &g, int n0,
         const hx8 yh = dense_tr_pair(Tb + yoff, 16 * TB);
         const hx8 yl = dense_tr_pair(Tb + yoff + TS, 16 * TB);
         dense_kblock_mma<F, (NBLK == 1 ? 8 : 4)>(acc, ihi, ilo, (32 * ib + 4 * L.mq + L.tq) * RS + 4 * L.tp, 16 * RS, yh, yl);
+      }
+    }
+    if constexpr (FR == F) {
+      if (!accumulate) {  // (wave-uniform) whole-line stores
+        dense_store_rows<FT>(acc, oscale, outb, (unsigned)hf, j, n, L);
+        return;
       }
     }
     if (j < n) dense_store_acc<FT, (FR < F)>(acc, oscale, outb, (unsigned)j * (unsigned)hf + 4u * L.mq, accumulate, 4 * L.mq, fr);
@@ -887,8 +906,9 @@ __device__ __forceinline__ void dense_bwd_body(float *lds, const Csr &g, int n0,
         }
         if (jc + 1 == NBLK) {  // dQ rows of this row block are complete: store them now, under the dK product
           const int i = i0 + wave * 16 + L.mi;
-          if (i < i0 + ni)
-            dense_store_acc<FT, (FR < F)>(qacc, kinv * ts.inv, dQb, (unsigned)i * (unsigned)hf + 4u * L.mq, false, 4 * L.mq, fr);
+          if constexpr (FR == F) dense_store_rows<FT>(qacc, kinv * ts.inv, dQb, (unsigned)hf, i, i0 + ni, L);
+          else if (i < i0 + ni)
+            dense_store_acc<FT, true>(qacc, kinv * ts.inv, dQb, (unsigned)i * (unsigned)hf + 4u * L.mq, false, 4 * L.mq, fr);
         }
       }
       DFGNN_DSTAMP(6)
@@ -945,10 +965,23 @@ __global__ __launch_bounds__(kDenseThreads) void gt_dense_bwd_kernel(
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int n0 = fit[2 * blockIdx.x], n1 = fit[2 * blockIdx.x + 1] & kPlanRangeMask;
   const int n = n1 - n0, e0 = g.row_ptr[n0], ne = g.row_ptr[n1] - e0;
-  if (n <= kDenseChunkRows)
+#ifdef DFGNN_BWD_VARIANT  // diagnostic builds: one geometry only (register use / ISA of a single body)
+  constexpr int only = DFGNN_BWD_VARIANT;
+#else
+  constexpr int only = -1;
+#endif
+  if ((only < 0 && n <= kDenseChunkRows) || only == 0)
+#ifdef DFGNN_RING128  // A/B builds: half-width images through the prefetch ring for the <= 128-node ranges as well
+    dense_bwd_wide_body<F, kDenseChunkRows, DFGNN_RING128, DFGNN_FW128>(lds, g, n0, n, e0, ne, blockIdx.y, Q, K, V, attn_edge, dO, dQ, dK, dV);
+#else
     dense_bwd_body<F, kDenseChunkRows, 1>(lds, g, n0, n, e0, ne, blockIdx.y, Q, K, V, attn_edge, dO, dQ, dK, dV);
-  else if (n <= kDenseWideRows)
+#endif
+  else if ((only < 0 && n <= kDenseWideRows) || only == 1)
+#ifdef DFGNN_OLD_WIDE_BWD  // A/B builds only: two row blocks of <= 80 rows, full-width images
     dense_bwd_body<F, kDenseWideRows, 1>(lds, g, n0, n, e0, ne, blockIdx.y, Q, K, V, attn_edge, dO, dQ, dK, dV);
+#else
+    dense_bwd_wide_body<F, kDenseWideRows, DFGNN_RING160>(lds, g, n0, n, e0, ne, blockIdx.y, Q, K, V, attn_edge, dO, dQ, dK, dV);
+#endif
   else
     dense_bwd_body<F, kDenseChunkRows, 2>(lds, g, n0, n, e0, ne, blockIdx.y, Q, K, V, attn_edge, dO, dQ, dK, dV);
 #ifdef DFGNN_STAMPS

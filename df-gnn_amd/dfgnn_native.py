@@ -8,7 +8,8 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdfgnn.so")
+# DFGNN_LIB=<file name>: an A/B build of the library next to the shipped one (tools/diag/build_variant.sh)
+LIB_PATH = os.path.join(_HERE, os.environ.get("DFGNN_LIB", "libdfgnn.so"))
 CSRC = os.path.join(_HERE, "csrc")
 
 _vp, _i, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
