@@ -7,10 +7,14 @@ One "step" = one pass of the hot path over one resident batch: GTConvFuse_hyper 
 DFGNN/script/train/train_batch_graph_timing.py times per layer in the reference.
 Inputs (CSR/COO/CSC index arrays, Q, K, V, dO) are resident in HBM before the timed region.
 
-N > 1: one process per GPU (torch.distributed, RCCL).  Whole graphs are the shard unit; each rank
-owns its own bs=1024 batch (weak scaling) and fwd+bwd needs no data-path collective (dQ/dK/dV of a
-graph depend only on that graph).  The forward-output all-gather that an inference caller may want is
-timed separately and reported under "inference_allgather" -- it is never part of `value`.
+N > 1: one process per GPU (torch.distributed, RCCL).  Whole graphs are the shard unit and fwd+bwd needs no
+data-path collective (dQ/dK/dV of a graph depend only on that graph).
+  --scaling weak   (default, the driver contract): every rank owns its own bs=1024 batch; `value` = all edges / time.
+  --scaling strong: the ONE seed-1 bs=1024 batch is cut into N shards of whole graphs, balanced by edge
+                   count (DFGNN/parallel/sharding.py:shard_graph); `value` = its edges / max-over-ranks time.
+With N > 1 the line also carries the other mode's measurement ("strong_scaling" / "weak_scaling") and the
+forward-output all-gather an inference caller may want ("inference_allgather": kernel + RCCL all-gather of the padded
+per-shard outputs) -- never part of `value`.
 
 Prints ONE JSON line on rank 0.
 """
@@ -30,6 +34,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md; ~6.3 TB/s is the measured copy rate)
+PMC_PROFILE = os.path.join("profiles", "r02_pmc_dense_kernels.json")  # HBM bytes per launch from rocprofv3 --pmc passes
 
 
 def parse():
@@ -40,7 +45,9 @@ def parse():
     ap.add_argument("--batch-size", type=int, default=1024)
     ap.add_argument("--dim", type=int, default=128)
     ap.add_argument("--heads", type=int, default=1)
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-c4", action="store_true", help="skip the reddit-like GAT 'tiling' secondary figure")
     ap.add_argument("--cpu-sample-graphs", type=int, default=128)
     # rehearsal only: "gloo" lets several ranks share ONE GPU (collectives on host tensors) to exercise the N > 1
     # code path on a single-GPU box; the driver's multi-GPU runs use the default (RCCL).
@@ -58,10 +65,52 @@ def algorithmic_bytes(m, nnz, h, f):
         # whole backward: reads Q,K,V,dO, attn_edge, CSR + CSC index arrays; writes dQ,dK,dV; the
         # reference's grad_edge round trip (8 h nnz) is part of the figure even though the resident kernel avoids it
         "gt_bwd": 28 * m * D + 12 * h * nnz + 16 * nnz + 8 * (m + 1),
-        # the two general (plan-less) backward launches, each reading its inputs once
-        "gt_bwd_rows(general)": 16 * m * D + 8 * h * nnz + 12 * nnz + 4 * (m + 1),
-        "gt_bwd_cols(general)": 16 * m * D + 8 * h * nnz + 12 * nnz + 4 * (m + 1),
     }
+
+
+def ev_us(fn, reps=10, warm=3):
+    """Mean device time of fn() in microseconds (events on torch's current stream = the launch stream)."""
+    for _ in range(warm):
+        fn()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    for a, b in evs:
+        a.record()
+        fn()
+        b.record()
+    torch.cuda.synchronize()
+    return float(np.mean([a.elapsed_time(b) for a, b in evs])) * 1e3
+
+
+def wall_ms(fn, reps=10, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps * 1e3
+
+
+class Workload:
+    """One rank's resident batch: graph structure (hyper format + CSC), features and the step closure."""
+
+    def __init__(self, g_host, h, f, feat_seed, dev):
+        from DFGNN.layers import preprocess_Hyper_fw_bw
+        from DFGNN.operators.fused_gtconv import GTConvFuse_hyper
+        from DFGNN.utils import synthetic as S
+        self.g_host, self.g = g_host, g_host.to(dev)
+        (_, self.rows, self.row_ptr, self.col_ind, self.val, self.col_ptr, self.row_ind, self.val_idx,
+         self.smem) = preprocess_Hyper_fw_bw(self.g)
+        self.m, self.nnz = self.g.num_nodes(), self.g.num_edges()
+        self.Q, self.K, self.V = (t.requires_grad_(True) for t in S.gt_features(self.m, h, f, seed=feat_seed, device=dev))
+        self.dO = torch.randn(self.m, h, f, generator=torch.Generator().manual_seed(7 + feat_seed)).to(dev)
+        self._op = GTConvFuse_hyper
+
+    def step(self):
+        out = self._op(self.rows, self.row_ptr, self.col_ind, self.val, self.col_ptr, self.row_ind, self.val_idx,
+                       self.smem, self.Q, self.K, self.V)
+        return torch.autograd.grad(out, (self.Q, self.K, self.V), self.dO)
 
 
 def main():
@@ -86,147 +135,191 @@ def main():
 
     import dfgnn_native
     import fused_gtconv
-    from DFGNN.layers import preprocess_Hyper_fw_bw
-    from DFGNN.operators.fused_gtconv import GTConvFuse_hyper
+    from DFGNN.parallel import shard_graph
     from DFGNN.utils import synthetic as S
 
     h, f = args.heads, args.dim // args.heads
-    # ---- workload: this rank's shard = its own PATTERN-like batch (whole graphs), resident in HBM
-    g_host = S.pattern_like(batch_size=args.batch_size, seed=1 + rank)
-    g = g_host.to(dev)
-    A, rows, row_ptr, col_ind, val, col_ptr, row_ind, val_idx, smem = preprocess_Hyper_fw_bw(g)
-    m, nnz = g.num_nodes(), g.num_edges()
-    Q, K, V = (t.requires_grad_(True) for t in S.gt_features(m, h, f, seed=100 + rank, device=dev))
-    dO = torch.randn(m, h, f, generator=torch.Generator().manual_seed(7 + rank)).to(dev)
-
-    def step():
-        out = GTConvFuse_hyper(rows, row_ptr, col_ind, val, col_ptr, row_ind, val_idx, smem, Q, K, V)
-        return torch.autograd.grad(out, (Q, K, V), dO)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
+    def allmax(x):
+        if world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        e = torch.tensor([nnz], dtype=torch.int64, device=cdev)
-        dist.all_reduce(e)
-        total_edges = int(e.item())
-    else:
-        total_edges = nnz
+        return float(t.item())
+
+    def allsum(x):
+        if world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.int64, device=cdev)
+        dist.all_reduce(t)
+        return int(t.item())
+
+    def make(scaling):
+        """This rank's workload: its own batch (weak) or its shard of the seed-1 batch (strong)."""
+        if scaling == "weak" or world == 1:
+            return Workload(S.pattern_like(batch_size=args.batch_size, seed=1 + (rank if scaling == "weak" else 0)), h, f,
+                            100 + rank, dev)
+        full = S.pattern_like(batch_size=args.batch_size, seed=1)
+        sub, _ = shard_graph(full, rank, world)
+        return Workload(sub, h, f, 100 + rank, dev)
+
+    def timed(w, steps, warmup):
+        for _ in range(warmup):
+            w.step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            w.step()
+        barrier()
+        return allmax(time.perf_counter() - t0)
+
+    # ---- the timed region -------------------------------------------------------------------------------------------
+    W = make(args.scaling)
+    m, nnz = W.m, W.nnz
+    elapsed = timed(W, args.steps, args.warmup)
+    total_edges = allsum(nnz)
     ms_per_step = elapsed / args.steps * 1e3
     value = total_edges * args.steps / elapsed
 
-    # ---- per-kernel attribution with device events on the launch stream (same inputs, K launches each)
+    # ---- the other scaling mode and the inference-side exchange step (N > 1 only) -------------------------------
+    other = gather = None
+    if world > 1:
+        other_mode = "strong" if args.scaling == "weak" else "weak"
+        Wo = make(other_mode)
+        t_o = timed(Wo, args.steps, args.warmup)
+        e_o = allsum(Wo.nnz)
+        other = {"ms_per_step": round(t_o / args.steps * 1e3, 4), "edges_per_s": e_o * args.steps / t_o,
+                 "total_edges": e_o, "edges_this_rank": Wo.nnz,
+                 "note": ("the seed-1 bs=%d batch cut into %d shards of whole graphs (shard_graph, edge-balanced); kernel time "
+                          "only, no collective on the fwd+bwd path" % (args.batch_size, world)) if other_mode == "strong"
+                 else "every rank its own bs=%d batch" % args.batch_size}
+        Ws = W if args.scaling == "strong" else Wo      # the all-gather belongs to the sharded-batch picture
+        mx = int(allmax(float(Ws.m)))
+        send = torch.zeros(mx, h, f, device=cdev)
+        recv = torch.empty(world * mx, h, f, device=cdev)
+
+        def infer_step():
+            o = fused_gtconv.gt_hyper_inference(Ws.row_ptr, Ws.col_ind, Ws.rows, Ws.val, Ws.smem, Ws.Q.detach(),
+                                                Ws.K.detach(), Ws.V.detach())[0]
+            send[:Ws.m].copy_(o)
+            if args.dist_backend == "nccl":
+                dist.all_gather_into_tensor(recv, send)
+            else:
+                dist.all_gather(list(recv.chunk(world)), send)
+
+        def infer_only():
+            fused_gtconv.gt_hyper_inference(Ws.row_ptr, Ws.col_ind, Ws.rows, Ws.val, Ws.smem, Ws.Q.detach(), Ws.K.detach(),
+                                            Ws.V.detach())
+
+        times = {}
+        for name, fn in (("kernel_plus_allgather", infer_step), ("kernel_only", infer_only)):
+            for _ in range(3):
+                fn()
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                fn()
+            barrier()
+            times[name] = allmax(time.perf_counter() - t0) / args.steps * 1e3
+        e_s = allsum(Ws.nnz)
+        gather = {"ms_per_step": round(times["kernel_plus_allgather"], 4), "ms_kernel_only": round(times["kernel_only"], 4),
+                  "edges_per_s": e_s / (times["kernel_plus_allgather"] * 1e-3), "gathered_MB_per_rank": round(world * mx * h * f * 4 / 1e6, 1),
+                  "workload": "forward (inference) of the sharded seed-1 batch, outputs padded to the largest shard, one "
+                              "all_gather_into_tensor"}
+
+    # ---- per-kernel attribution with device events on the launch stream (same inputs) -----------------------------
     L = dfgnn_native.lib()
     P = lambda t: t.data_ptr()  # noqa: E731
     stream = torch.cuda.current_stream(dev).cuda_stream
     with torch.no_grad():
-        out = torch.empty_like(Q)
+        out = torch.empty_like(W.Q)
         attn = torch.empty(h, nnz, device=dev)
         gedge = torch.empty(h, nnz, device=dev)
-        dQ, dK, dV = torch.empty_like(Q), torch.empty_like(Q), torch.empty_like(Q)
+        dQ, dK, dV = torch.empty_like(W.Q), torch.empty_like(W.Q), torch.empty_like(W.Q)
     from _binding_util import get_plan, val_ptr
-    plan, plan_meta, _ = get_plan(row_ptr, col_ind, f, fused_gtconv.USE_BLOCK_PLAN)
-    VP = val_ptr(val)  # NULL for unit edge values, exactly as the binding passes it (fused_gtconv.py)
-    calls = {
-        "gt_hyper_fwd": lambda: L.dfgnn_gt_hyper_fwd(m, nnz, h, f, P(row_ptr), P(col_ind), P(rows), VP, P(Q), P(K),
-                                                     P(V), P(attn), None, P(out), plan, plan_meta, stream),
-        "gt_bwd": lambda: L.dfgnn_gt_bwd(m, nnz, h, f, P(row_ptr), P(col_ind), P(rows), VP, P(col_ptr), P(row_ind),
-                                         P(val_idx), P(Q), P(K), P(V), P(attn), P(dO), P(gedge), P(dQ), P(dK), P(dV),
-                                         plan, plan_meta, stream),
-        "gt_bwd_rows(general)": lambda: L.dfgnn_gt_bwd_rows(m, nnz, h, f, P(row_ptr), P(col_ind), P(rows), P(val), P(K), P(V),
-                                                   P(attn), P(dO), P(gedge), P(dQ), stream),
-        "gt_bwd_cols(general)": lambda: L.dfgnn_gt_bwd_cols(m, nnz, h, f, P(val), P(col_ptr), P(row_ind), P(val_idx), P(Q),
-                                                   P(attn), P(gedge), P(dO), P(dK), P(dV), stream),
-    }
-    kernel_us = {}
+    plan, plan_meta, _ = get_plan(W.row_ptr, W.col_ind, f, fused_gtconv.USE_BLOCK_PLAN)
+    VP = val_ptr(W.val)  # NULL for unit edge values, exactly as the binding passes it (fused_gtconv.py)
+
+    def fwd_call(vp):
+        return lambda: L.dfgnn_gt_hyper_fwd(m, nnz, h, f, P(W.row_ptr), P(W.col_ind), P(W.rows), vp, P(W.Q), P(W.K), P(W.V),
+                                            P(attn), None, P(out), plan, plan_meta, stream)
+
+    def bwd_call(vp):
+        return lambda: L.dfgnn_gt_bwd(m, nnz, h, f, P(W.row_ptr), P(W.col_ind), P(W.rows), vp, P(W.col_ptr), P(W.row_ind),
+                                      P(W.val_idx), P(W.Q), P(W.K), P(W.V), P(attn), P(W.dO), P(gedge), P(dQ), P(dK), P(dV),
+                                      plan, plan_meta, stream)
+
+    def checked(call):
+        def run():
+            assert call() == 0
+        return run
+
     reps = max(10, args.steps)
-    for name, call in calls.items():
-        for _ in range(3):
-            assert call() == 0
-        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
-        for a, b in evs:
-            a.record()
-            assert call() == 0
-            b.record()
-        torch.cuda.synchronize()
-        kernel_us[name] = float(np.mean([a.elapsed_time(b) for a, b in evs])) * 1e3
+    kernel_us = {"gt_hyper_fwd": ev_us(checked(fwd_call(VP)), reps), "gt_bwd": ev_us(checked(bwd_call(VP)), reps)}
+    # the same two launches with the edge values passed explicitly (val != NULL): the matrix-core kernels step aside and
+    # every product is an fp32 FMA on the VALU (the LDS-resident edge-walking kernels) -- the plain-f32 reference point
+    valu_us = {"gt_hyper_fwd": ev_us(checked(fwd_call(P(W.val))), reps), "gt_bwd": ev_us(checked(bwd_call(P(W.val))), reps)}
     abytes = algorithmic_bytes(m, nnz, h, f)
     dom = max(("gt_hyper_fwd", "gt_bwd"), key=kernel_us.get)  # the launches the timed step actually runs
     achieved = abytes[dom] / (kernel_us[dom] * 1e-6) / 1e9
-    # HBM bytes per launch from PMC counters (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc passes on this
-    # exact workload; profiles/r01_pmc_dense_kernels.json).  bench.py cannot collect counters itself, so the figure
-    # is reported only when the workload matches the profiled one, else null.
-    traffic = None
+    # HBM bytes per launch from PMC counters (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc passes over this exact
+    # workload and build, committed under profiles/): bench.py cannot collect counters itself, so the figure is quoted
+    # from that file -- with its name -- only when workload and library build match, else null.
+    traffic = traffic_src = None
     try:
-        prof = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_dense_kernels.json")))
-        if f"m={m}, nnz={nnz}" in prof["workload"] and h == 1 and f == 128:
+        prof = json.load(open(os.path.join(ROOT, PMC_PROFILE)))
+        if prof.get("m") == m and prof.get("nnz") == nnz and prof.get("h") == h and prof.get("f") == f:
             key = {"gt_hyper_fwd": "gt_dense_fwd_kernel", "gt_bwd": "gt_dense_bwd_kernel"}[dom]
             traffic = int(prof["traffic"][key]["total_bytes"])
+            traffic_src = PMC_PROFILE + (" (library build %s)" % prof.get("build_id", "?"))
     except Exception:
-        traffic = None
+        traffic = traffic_src = None
     roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "algorithmic_bytes": abytes[dom], "avg_us": round(kernel_us[dom], 2),
                 "all_kernels": {k: {"avg_us": round(v, 2), "algorithmic_bytes": abytes[k],
-                                    "achieved_GBs": round(abytes[k] / (v * 1e-6) / 1e9, 1)}
+                                    "achieved_GBs": round(abytes[k] / (v * 1e-6) / 1e9, 1),
+                                    "frac": round(abytes[k] / (v * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
                                 for k, v in kernel_us.items()}}
+    valu_step_us = valu_us["gt_hyper_fwd"] + valu_us["gt_bwd"]
+    arithmetic = {
+        "io": "f32", "accumulate": "f32",
+        "products": "matrix cores (v_mfma_f32_16x16x32_f16): every operand as fp16 hi + lo halves under a power-of-two scale, "
+                    "hi*hi + hi*lo + lo*hi accumulated in fp32 (~3 x 2^-24 relative error per product, that of an fp32 FMA "
+                    "chain; tests/test_gpu_parity.py::test_dense_kernels_are_fp32_equivalent)",
+        "f32_valu_step": {"what": "the same fwd+bwd launches with every product as an fp32 FMA on the VALU (edge values "
+                                  "passed explicitly, so the matrix-core kernels step aside)",
+                          "fwd_us": round(valu_us["gt_hyper_fwd"], 2), "bwd_us": round(valu_us["gt_bwd"], 2),
+                          "edges_per_s": nnz / (valu_step_us * 1e-6),
+                          "frac_fwd": round(abytes["gt_hyper_fwd"] / (valu_us["gt_hyper_fwd"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                          "frac_bwd": round(abytes["gt_bwd"] / (valu_us["gt_bwd"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}}
 
-    # ---- secondary figures on the same resident batch (never part of `value`): the GAT training pair (SURVEY.md 8f
-    #      rank 1), the per-batch preprocessing the reference counts inside an epoch (8f rank 2), and the timed step
-    #      replayed as one HIP graph
+    # ---- secondary figures (never part of `value`), rank 0 at N = 1 only ----------------------------------------
     secondary = None
     if rank == 0 and world == 1:
         import dfgnn_preprocess
         import fused_gatconv
         from _binding_util import build_plan
         from DFGNN.utils import GraphedStep
-
-        def ev_us(fn, reps=10):
-            for _ in range(3):
-                fn()
-            evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
-            for a, b in evs:
-                a.record()
-                fn()
-                b.record()
-            torch.cuda.synchronize()
-            return float(np.mean([a.elapsed_time(b) for a, b in evs])) * 1e3
-
-        def wall_ms(fn, reps=10):
-            for _ in range(3):
-                fn()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(reps):
-                fn()
-            torch.cuda.synchronize()
-            return (time.perf_counter() - t0) / reps * 1e3
-
         with torch.no_grad():
             ar, ac, X = S.gat_features(m, h, f, seed=6, device=dev)
-            go, emax, esum, mask = fused_gatconv.gat_forward(ar, ac, row_ptr, col_ind, 0.2, X, 0.0)
-            gat_f = ev_us(lambda: fused_gatconv.gat_forward(ar, ac, row_ptr, col_ind, 0.2, X, 0.0))
-            gat_b = ev_us(lambda: fused_gatconv.gat_backward(0.2, 0.0, row_ptr, col_ind, col_ptr, row_ind, val_idx, emax,
-                                                             esum, mask, X, ar, ac, dO))
-        src, dst = g.edges()
+            go, emax, esum, mask = fused_gatconv.gat_forward(ar, ac, W.row_ptr, W.col_ind, 0.2, X, 0.0)
+            gat_f = ev_us(lambda: fused_gatconv.gat_forward(ar, ac, W.row_ptr, W.col_ind, 0.2, X, 0.0))
+            gat_b = ev_us(lambda: fused_gatconv.gat_backward(0.2, 0.0, W.row_ptr, W.col_ind, W.col_ptr, W.row_ind, W.val_idx,
+                                                             emax, esum, mask, X, ar, ac, W.dO))
+        src, dst = W.g.edges()
 
         def raw_step():  # the launches of the timed step as explicit operator calls (no autograd bookkeeping)
             with torch.no_grad():
-                o, at = fused_gtconv.gt_hyper_forward(row_ptr, col_ind, rows, val, col_ptr, row_ind, val_idx, smem, Q, K, V)
-                return fused_gtconv.gt_backward(row_ptr, col_ind, rows, val, col_ptr, row_ind, val_idx, smem, Q, K, V, at, dO)
+                o, at = fused_gtconv.gt_hyper_forward(W.row_ptr, W.col_ind, W.rows, W.val, W.col_ptr, W.row_ind, W.val_idx,
+                                                      W.smem, W.Q, W.K, W.V)
+                return fused_gtconv.gt_backward(W.row_ptr, W.col_ind, W.rows, W.val, W.col_ptr, W.row_ind, W.val_idx, W.smem,
+                                                W.Q, W.K, W.V, at, W.dO)
 
         graphed = GraphedStep(raw_step)
         secondary = {
@@ -234,53 +327,25 @@ def main():
                           "edges_per_s": nnz / ((gat_f + gat_b) * 1e-6)},
             "preprocess_per_batch_ms": {
                 "coo_to_csr_csc_native": round(wall_ms(lambda: dfgnn_preprocess.coo_to_hyper(src, dst, m, csc=True)), 3),
-                "block_plan": round(wall_ms(lambda: build_plan(row_ptr, col_ind, f)), 3)},
+                "block_plan": round(wall_ms(lambda: build_plan(W.row_ptr, W.col_ind, f)), 3)},
             "step_as_hipgraph_ms": round(wall_ms(graphed.replay, reps=max(10, args.steps)), 4),
         }
+        if not args.no_c4:
+            secondary["c4"] = bench_c4(dev)
 
-    # ---- forward-output all-gather (the inference-side exchange step), timed separately
-    gather = None
-    if world > 1:
-        mx = torch.tensor([m], dtype=torch.int64, device=cdev)
-        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
-        m_pad = int(mx.item())
-        send = torch.zeros(m_pad, h, f, device=cdev)
-        recv = torch.empty(world * m_pad, h, f, device=cdev)
-
-        def infer_step():
-            o = fused_gtconv.gt_hyper_inference(row_ptr, col_ind, rows, val, smem, Q.detach(), K.detach(), V.detach())[0]
-            send[:m].copy_(o)
-            if args.dist_backend == "nccl":
-                dist.all_gather_into_tensor(recv, send)
-            else:
-                dist.all_gather(list(recv.chunk(world)), send)
-
-        for _ in range(3):
-            infer_step()
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            infer_step()
-        barrier()
-        tg = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=cdev)
-        dist.all_reduce(tg, op=dist.ReduceOp.MAX)
-        gather = {"ms_per_step": round(float(tg.item()) / args.steps * 1e3, 4),
-                  "edges_per_s": total_edges * args.steps / float(tg.item()),
-                  "gathered_MB_per_rank": round(world * m_pad * h * f * 4 / 1e6, 1)}
-
-    # ---- CPU baseline: the oracle's fp32 OpenMP build on a bounded sample of the same workload
+    # ---- CPU baseline: the oracle's fp32 OpenMP build on a bounded sample of the same workload -------------------
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:  # (the contract: rank 0 at N = 1 only)
         import oracle
         oracle.build()
         ng = min(args.cpu_sample_graphs, args.batch_size)
-        sizes = g_host.batch_num_nodes().numpy()
+        sizes = W.g_host.batch_num_nodes().numpy()
         n_s = int(sizes[:ng].sum())
-        rp = row_ptr[: n_s + 1].cpu().numpy()
+        rp = W.row_ptr[: n_s + 1].cpu().numpy()
         e_s = int(rp[-1])
-        ci = col_ind[:e_s].cpu().numpy()
-        vl = val[:e_s].cpu().numpy()
-        q, k, v, do = (t[:n_s].detach().cpu().numpy() for t in (Q, K, V, dO))
+        ci = W.col_ind[:e_s].cpu().numpy()
+        vl = W.val[:e_s].cpu().numpy()
+        q, k, v, do = (t[:n_s].detach().cpu().numpy() for t in (W.Q, W.K, W.V, W.dO))
         oracle.gt_forward(rp, ci, vl, q, k, v, acc="f32")  # warm-up
         t0 = time.perf_counter()
         n_rep = 0
@@ -299,14 +364,16 @@ def main():
         line = {
             "metric": "edges/s (fwd+bwd) fused GT conv, PATTERN bs=1024 dim=128",
             "value": value, "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": args.scaling if world > 1 else "weak",
+            "vs_baseline": None, "dtype": "f32", "arithmetic": arithmetic, "data": "synthetic",
             "config": {"workload": f"GT conv 'hyper' fwd+bwd, PATTERN-like batch bs={args.batch_size} "
                                    f"dim={args.dim} heads={h} (BASELINE.json configs[2])",
                        "nodes_per_gpu": m, "edges_per_gpu": nnz, "total_edges": total_edges,
-                       "parallelism": f"graph-sharded x{world}, no data-path collective"},
+                       "parallelism": (f"graph-sharded x{world} ({args.scaling} scaling), no data-path collective")},
             "roofline": roofline, "cpu_baseline": cpu,
         }
+        if other:
+            line["strong_scaling" if args.scaling == "weak" else "weak_scaling"] = other
         if gather:
             line["inference_allgather"] = gather
         if secondary:
@@ -314,6 +381,30 @@ def main():
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()
+
+
+def bench_c4(dev):
+    """BASELINE.json configs[3]: GAT 'tiling' on the reddit-like super-node graph (232 965 nodes, 114.6 M edges, f = 128),
+    single GPU; edges/s, achieved-HBM fraction (algorithmic bytes) and the row-gather rate that physically bounds it."""
+    from DFGNN.layers.util import preprocess_CSR
+    from DFGNN.operators import fused_gatconv as gat
+    from DFGNN.utils import synthetic as S
+    t0 = time.perf_counter()
+    g = S.reddit_like().to(dev)
+    row_ptr, col_ind, val, _ = preprocess_CSR(g)
+    m, nnz = g.num_nodes(), g.num_edges()
+    build_s = time.perf_counter() - t0
+    ar, ac, X = S.gat_features(m, 1, 128, seed=4, device=dev)
+    us = ev_us(lambda: gat.GATConvFuse_inference_tiling(ar, ac, row_ptr, col_ind, 0.2, X), reps=5, warm=2)
+    byt = 8 * m * 128 + 8 * m + 4 * (m + 1) + 4 * nnz
+    deg = row_ptr[1:] - row_ptr[:-1]
+    res = {"workload": "GAT conv 'tiling' on a reddit-like graph, dim=128 (BASELINE.json configs[3])", "nodes": m,
+           "edges": nnz, "max_degree": int(deg.max()), "ms": round(us / 1e3, 3), "edges_per_s": nnz / (us * 1e-6),
+           "algorithmic_bytes": byt, "hbm_frac": round(byt / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+           "gather_GBs": round(nnz * 512 / (us * 1e-6) / 1e9, 1), "graph_build_s": round(build_s, 1)}
+    del g, row_ptr, col_ind, val, ar, ac, X
+    torch.cuda.empty_cache()
+    return res
 
 
 if __name__ == "__main__":
