@@ -57,6 +57,13 @@ def val_ptr(val):
         return None
     cached = getattr(val, "_dfgnn_unit", None)
     if cached is None or cached[0] != val._version:
+        # Preprocessing marks the arrays it creates (DFGNN/layers/util.py:_unit_val), so flows that follow the
+        # reference never get here; a foreign tensor is tested once (one reduction + host sync), which cannot happen
+        # inside a stream capture.
+        if val.is_cuda and torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("edge values of unknown content inside a HIP-graph capture: run the operator once before "
+                               "capturing (or create `val` through DFGNN.layers.preprocess_*), so that the all-ones test "
+                               "is cached on the tensor")
         cached = (val._version, bool((val == 1).all().item()) if val.numel() else True)
         try:
             val._dfgnn_unit = cached
@@ -116,8 +123,11 @@ def get_plan(indptr, indices, f, enable=True):
     reference's preprocess_* tuples keep that tensor alive across the layers / epochs that reuse a batch
     (DFGNN/layers/util.py:82-142), so the plan is built once per batch structure.
     Returns (plan_ptr, meta_ptr, needs_edge_scratch) for the C ABI, or (None, None, False)."""
-    if not enable or f % 4 != 0 or indices.size(0) == 0:
+    if not enable or f <= 0 or f % 4 != 0 or indices.dim() != 1 or indptr.dim() != 1 or indices.size(0) == 0:
         return None, None, False
+    if not (indptr.is_cuda and indices.is_cuda and indptr.dtype == torch.int32 and indices.dtype == torch.int32 and
+            indptr.is_contiguous() and indices.is_contiguous()):
+        return None, None, False  # (the binding's argument checks raise the matching error right after)
     if indices.size(0) < 8 * (indptr.size(0) - 1):
         return None, None, False  # low-degree graphs take the row-per-lane-group kernels (capi.hip:low_degree)
     key = (indices.data_ptr(), indices.size(0), indptr._version, indices._version, f)

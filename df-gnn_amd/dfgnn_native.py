@@ -34,7 +34,10 @@ SIGNATURES = {
     "dfgnn_gat_bwd": [_i, _i, _i, _i] + [_vp] * 8 + [_f] + [_vp] * 4 + [_f] + [_vp] * 8,
 }
 
+EXT_PATH = os.path.join(_HERE, "_dfgnn_ext.so")   # torch C++ extension over the same C ABI (csrc/torch_ext.cpp)
+
 _lib = None
+_ext = False
 
 
 def source_hash():
@@ -98,6 +101,25 @@ def lib():
         L.dfgnn_preprocess_ws_bytes.restype = ctypes.c_size_t
         _lib = L
     return _lib
+
+
+def ext():
+    """The torch C++ extension (csrc/torch_ext.cpp -> _dfgnn_ext.so, built in-tree by build()): the reference-style
+    pybind11 binding over the same C ABI, ~5 us of host time per operator call instead of ~25-60 for ctypes.  None when
+    it is absent, does not belong to this library build, or DFGNN_BINDING=ctypes asks for the ctypes path (tests)."""
+    global _ext
+    if _ext is False:
+        _ext = None
+        if os.environ.get("DFGNN_BINDING", "ext") != "ctypes" and os.path.exists(EXT_PATH) and \
+                os.path.basename(LIB_PATH) == "libdfgnn.so":
+            import importlib.util
+            L = lib()  # libdfgnn.so first (and torch before it): the extension resolves its dfgnn_* symbols against it
+            spec = importlib.util.spec_from_file_location("_dfgnn_ext", EXT_PATH)
+            mod = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(mod)
+            if mod.abi_version() == L.dfgnn_abi_version() and mod.build_id() == L.dfgnn_build_id().decode():
+                _ext = mod
+    return _ext
 
 
 def check(code, what):

@@ -42,6 +42,11 @@ def _check(attn_row, attn_col, indptr, indices, rows, in_feat):
 
 def gat_inference_hyper(smem_consume, attn_row, attn_col, indptr, indices, rows, negative_slope, in_feat):
     """fused_gatconv.cpp:99-119 -> Tensor out[m, h, f]"""
+    ext = _n.ext()
+    if ext is not None:  # torch C++ binding (csrc/torch_ext.cpp): same checks, same C ABI call
+        plan, meta, need_ws = get_plan(indptr, indices, in_feat.size(-1) if in_feat.dim() == 3 else 0, USE_BLOCK_PLAN)
+        return ext.gat_hyper_fwd(attn_row, attn_col, indptr, indices, rows, float(negative_slope), in_feat, plan or 0,
+                                 meta or 0, need_ws)
     m, nnz, h, f = _check(attn_row, attn_col, indptr, indices, rows, in_feat)
     with torch.cuda.device(in_feat.device):
         out = torch.empty_like(in_feat)
@@ -60,6 +65,10 @@ def gat_inference_hyper_ablation(smem_consume, attn_row, attn_col, indptr, indic
 
 
 def _softmax(fn_name, what, attn_row, attn_col, indptr, indices, rows, negative_slope, in_feat):
+    ext = _n.ext()
+    if ext is not None:
+        return ext.gat_softmax_fwd(attn_row, attn_col, indptr, indices, rows, float(negative_slope), in_feat,
+                                   fn_name == "dfgnn_gat_softmax_fwd")
     m, nnz, h, f = _check(attn_row, attn_col, indptr, indices, rows, in_feat)
     with torch.cuda.device(in_feat.device):
         out = torch.empty_like(in_feat)
@@ -84,6 +93,9 @@ def gat_inference_softmax_gm(attn_row, attn_col, indptr, indices, rows, negative
 
 def gat_inference_tiling(attn_row, attn_col, row_ptr, col_ind, negative_slope, in_feat):
     """fused_gatconv.cpp:196-219 -> Tensor"""
+    ext = _n.ext()
+    if ext is not None:
+        return ext.gat_tiling_fwd(attn_row, attn_col, row_ptr, col_ind, float(negative_slope), in_feat)
     m, nnz, h, f = _check(attn_row, attn_col, row_ptr, col_ind, None, in_feat)
     with torch.cuda.device(in_feat.device):
         out = torch.empty_like(in_feat)

@@ -46,6 +46,10 @@ def _check_edges(nnz, **arrs):
 
 def gt_hyper_inference(indptr, indices, rows, val, smem_consume, Q, K, V):
     """fused_gtconv.cpp:278-314 -> [out]"""
+    ext = _n.ext()
+    if ext is not None:  # torch C++ binding (csrc/torch_ext.cpp): same checks, same C ABI call
+        plan, meta, _ = get_plan(indptr, indices, Q.size(-1) if Q.dim() == 3 else 0, USE_BLOCK_PLAN)
+        return ext.gt_hyper_fwd(indptr, indices, rows, val, Q, K, V, False, val_ptr(val) is None, plan or 0, meta or 0)
     check_device(indptr=indptr, indices=indices, rows=rows, val=val)
     check_contiguous(indptr=indptr, indices=indices, rows=rows, val=val)
     check_dtype(torch.int32, indptr=indptr, indices=indices, rows=rows)
@@ -57,8 +61,7 @@ def gt_hyper_inference(indptr, indices, rows, val, smem_consume, Q, K, V):
     with torch.cuda.device(Q.device):
         out = torch.empty_like(Q)
         plan, meta, need_ws = get_plan(indptr, indices, f, USE_BLOCK_PLAN)
-        # scratch for per-edge values: required when the plan has edge-global ranges, and it lets mid-size ranges
-        # use the matrix-core logits path (their per-edge array moves out of LDS to make room for the tile panel)
+        # scratch for per-edge values: required when the plan has edge-global ranges
         ws = torch.empty((h, nnz), dtype=torch.float32, device=Q.device) if plan is not None else None
         _n.check(_n.lib().dfgnn_gt_hyper_fwd(m, nnz, h, f, ptr(indptr), ptr(indices), ptr(rows), val_ptr(val),
                                              ptr(Q), ptr(K), ptr(V), None, ptr(ws), ptr(out), plan, meta,
@@ -74,6 +77,10 @@ def gt_hyper_inference_ablation(indptr, indices, rows, val, smem_consume, Q, K, 
 
 def gt_hyper_forward(row_ptr, col_ind, rows, val, col_ptr, row_ind, val_idx, smem_consume, Q, K, V):
     """fused_gtconv.cpp:79-116 -> [out, attn_edge[h, nnz]] (training forward)."""
+    ext = _n.ext()
+    if ext is not None:
+        plan, meta, _ = get_plan(row_ptr, col_ind, Q.size(-1) if Q.dim() == 3 else 0, USE_BLOCK_PLAN)
+        return ext.gt_hyper_fwd(row_ptr, col_ind, rows, val, Q, K, V, True, val_ptr(val) is None, plan or 0, meta or 0)
     check_device(row_ptr=row_ptr, col_ind=col_ind, val=val, rows=rows)
     check_contiguous(row_ptr=row_ptr, col_ind=col_ind, val=val, rows=rows)
     check_dtype(torch.int32, row_ptr=row_ptr, col_ind=col_ind, rows=rows)
@@ -96,6 +103,11 @@ def gt_backward(row_ptr, col_ind, rows, val, col_ptr, row_ind, val_idx, smem_con
                 grad):
     """fused_gtconv.cpp:125-172 -> [dQ, dK, dV]."""
     val_idx = as_int32(val_idx)
+    ext = _n.ext()
+    if ext is not None:
+        plan, meta, _ = get_plan(row_ptr, col_ind, Q.size(-1) if Q.dim() == 3 else 0, USE_BLOCK_PLAN)
+        return ext.gt_bwd(row_ptr, col_ind, rows, val, col_ptr, row_ind, val_idx, Q, K, V, attn_edge, grad,
+                          val_ptr(val) is None, plan or 0, meta or 0)
     check_device(row_ptr=row_ptr, col_ind=col_ind, rows=rows, val=val, col_ptr=col_ptr, row_ind=row_ind,
                  val_idx=val_idx, attn_edge=attn_edge, grad=grad)
     check_contiguous(row_ptr=row_ptr, col_ind=col_ind, rows=rows, val=val, col_ptr=col_ptr, row_ind=row_ind,

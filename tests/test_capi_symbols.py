@@ -50,3 +50,17 @@ def test_library_is_built_from_the_sources_on_disk():
     libdfgnn.so cannot pass for a fresh one just because its ABI number matches."""
     import dfgnn_native
     assert dfgnn_native.build_id() == dfgnn_native.source_hash()
+
+
+def test_torch_extension_binds_the_same_c_abi():
+    """_dfgnn_ext.so (csrc/torch_ext.cpp, the torch/extension.h shim) imports nothing but dfgnn_* symbols that
+    include/dfgnn.h declares and libdfgnn.so exports, and was built against this library build."""
+    import subprocess
+    import dfgnn_native
+    assert os.path.exists(dfgnn_native.EXT_PATH), "_dfgnn_ext.so missing: run __graft_entry__.build()"
+    out = subprocess.run(["nm", "-D", "--undefined-only", dfgnn_native.EXT_PATH], capture_output=True, text=True, check=True).stdout
+    used = sorted({ln.split()[-1] for ln in out.splitlines() if " dfgnn_" in ln})
+    assert "dfgnn_gt_hyper_fwd" in used and "dfgnn_gt_bwd" in used and "dfgnn_gat_softmax_fwd" in used
+    assert set(used) <= set(_declared())
+    ext = dfgnn_native.ext()
+    assert ext is not None and ext.abi_version() == 6 and ext.build_id() == dfgnn_native.source_hash()

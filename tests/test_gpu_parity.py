@@ -1018,6 +1018,74 @@ def test_hipgraph_capture_of_a_training_step(shape):
     assert not torch.equal(again[0], eager[0])
 
 
+def test_torch_extension_and_ctypes_bindings_agree():
+    """The torch C++ extension (csrc/torch_ext.cpp) and the ctypes binding end in the same C ABI calls: bit-identical
+    results for every entry point the extension serves, the same RuntimeError for a bad argument, and the extension is
+    the one the operator modules use."""
+    import dfgnn_native
+    import fused_gatconv as gat
+    import fused_gtconv as gt
+    from DFGNN.layers import preprocess_Hyper_fw_bw
+    from DFGNN.utils import synthetic as S
+    assert dfgnn_native.ext() is not None
+    g = S.pattern_like(batch_size=12, seed=8).to(DEV)
+    A, rows, row_ptr, col_ind, val, col_ptr, row_ind, val_idx, smem = preprocess_Hyper_fw_bw(g)
+    m = g.num_nodes()
+    Q, K, V = S.gt_features(m, 2, 64, seed=1, device=DEV)
+    dO = torch.randn_like(Q)
+    ar, ac, X = S.gat_features(m, 2, 64, seed=2, device=DEV)
+
+    def run():
+        out, attn = gt.gt_hyper_forward(row_ptr, col_ind, rows, val, col_ptr, row_ind, val_idx, smem, Q, K, V)
+        res = [out, attn] + list(gt.gt_backward(row_ptr, col_ind, rows, val, col_ptr, row_ind, val_idx, smem, Q, K, V, attn, dO))
+        res += gt.gt_hyper_inference(row_ptr, col_ind, rows, val, smem, Q, K, V)
+        res += [gat.gat_inference_hyper(smem, ar, ac, row_ptr, col_ind, rows, 0.2, X),
+                gat.gat_inference_softmax(smem, ar, ac, row_ptr, col_ind, rows, 0.2, X),
+                gat.gat_inference_softmax_gm(ar, ac, row_ptr, col_ind, rows, 0.2, X),
+                gat.gat_inference_tiling(ar, ac, row_ptr, col_ind, 0.2, X)]
+        try:
+            gt.gt_hyper_inference(row_ptr, col_ind, rows.long(), val, smem, Q, K, V)
+            err = None
+        except RuntimeError as e:
+            err = str(e)
+        return res, err
+
+    via_ext, err_ext = run()
+    saved = dfgnn_native._ext
+    dfgnn_native._ext = None                      # force the ctypes path
+    try:
+        via_ctypes, err_ctypes = run()
+    finally:
+        dfgnn_native._ext = saved
+    assert len(via_ext) == len(via_ctypes) == 10
+    for a, b in zip(via_ext, via_ctypes):
+        assert torch.equal(a, b)
+    assert err_ext and err_ctypes and "int32" in err_ext and "int32" in err_ctypes
+
+
+def test_hipgraph_refuses_autograd_callables():
+    """GraphedStep captures explicit operator calls; a callable that runs the autograd engine (the round-1 crash in
+    hipStreamEndCapture, DFGNN/utils/hipgraph.py) is refused with a RuntimeError before any capture starts."""
+    from DFGNN.layers import preprocess_Hyper_fw_bw
+    from DFGNN.operators.fused_gtconv import GTConvFuse_hyper
+    from DFGNN.utils import GraphedStep
+    from DFGNN.utils import synthetic as S
+    g = S.pattern_like(batch_size=4, seed=2).to(DEV)
+    A, rows, row_ptr, col_ind, val, col_ptr, row_ind, val_idx, smem = preprocess_Hyper_fw_bw(g)
+    Q, K, V = (t.requires_grad_(True) for t in S.gt_features(g.num_nodes(), 1, 64, seed=1, device=DEV))
+    dO = torch.randn_like(Q)
+
+    def autograd_step():
+        out = GTConvFuse_hyper(rows, row_ptr, col_ind, val, col_ptr, row_ind, val_idx, smem, Q, K, V)
+        return torch.autograd.grad(out, (Q, K, V), dO)
+
+    with pytest.raises(RuntimeError, match="explicit operator calls"):
+        GraphedStep(autograd_step)
+    assert not torch.cuda.is_current_stream_capturing()
+    out = GTConvFuse_hyper(rows, row_ptr, col_ind, val, col_ptr, row_ind, val_idx, smem, Q, K, V)   # the device is fine
+    assert torch.isfinite(out).all()
+
+
 @pytest.mark.parametrize("h,f,batched", [(1, 128, True), (4, 32, True), (2, 20, False), (3, 7, False)])
 def test_gat_hyper_v2_and_recompute(oracle_mod, h, f, batched):
     """gat_inference_hyper_v2 (scores kernel + conv, multi-head a_l / a_r handed over as the
