@@ -17,6 +17,7 @@ from DFGNN.utils import sparse as dglsp
 
 from .AGNN import (AGNNConv_csr, AGNNConv_csr_gm, AGNNConv_hyper, AGNNConv_softmax, AGNNConv_softmax_gm,
                    AGNNConv_tiling)
+from .GAT_DOT import DOTGATConv_csr, DOTGATConv_hyper, DOTGATConv_softmax
 from .GAT import (GATConv_dgNN, GATConv_hyper, GATConv_hyper_ablation, GATConv_hyper_recompute, GATConv_hyper_v2,
                   GATConv_softmax, GATConv_softmax_gm, GATConv_tiling)
 from .GT import (SparseMHA_CSR, SparseMHA_CSR_GM, SparseMHA_forward_timing, SparseMHA_hyper, SparseMHA_softmax,
@@ -113,6 +114,7 @@ _AGNN_LAYERS = {  # reference :424-442
     "hyper": AGNNConv_hyper, "csr": AGNNConv_csr, "softmax": AGNNConv_softmax, "csr_gm": AGNNConv_csr_gm,
     "tiling": AGNNConv_tiling, "softmax_gm": AGNNConv_softmax_gm,
 }
+_DOTGAT_LAYERS = {"hyper": DOTGATConv_hyper, "csr": DOTGATConv_csr, "softmax": DOTGATConv_softmax}
 # formats of the reference that are baselines on NVIDIA-only libraries or paper experiments
 _OUT_OF_SCOPE = {"hybrid", "pyg", "cugraph", "subgraph"}
 
@@ -137,7 +139,15 @@ def load_layer_AGNN(args):
     return _pick(_AGNN_LAYERS, args, "AGNNconv")
 
 
+def load_layer_DOTGAT(args):
+    """The reference ships the DOTGAT layer classes (DFGNN/layers/GAT_DOT) without a `--conv` entry; `--conv dotgat` is
+    this build's addition.  Its layers take (g, *preprocess tuple): load_prepfunc(args) wraps the graph in."""
+    return _pick(_DOTGAT_LAYERS, args, "DOTGATconv")
+
+
 def load_graphconv_layer(args):
+    if args.conv == "dotgat":
+        return load_layer_DOTGAT(args)
     if args.conv == "gat":
         return load_layer_GAT(args)
     if args.conv == "agnn":
@@ -148,6 +158,9 @@ def load_graphconv_layer(args):
 
 
 def load_prepfunc(args):
+    if getattr(args, "conv", None) == "dotgat":
+        inner = {"csr": preprocess_CSR, "hyper": preprocess_Hyper, "softmax": preprocess_softmax}[args.format]
+        return lambda g, **kw: (g,) + tuple(inner(g, **kw))
     if args.format in ("csr", "csr_gm", "tiling"):
         return preprocess_CSR
     if args.format in ("hyper", "nofuse", "hyper_ablation", "hyper_recompute", "hyper_v2"):

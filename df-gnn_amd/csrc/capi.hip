@@ -19,7 +19,7 @@ inline bool make_plan(Plan &p, const int *plan_dev, const int *meta, int m, int 
   // by the per-edge gathers: a 1024-thread workgroup per range only adds fixed cost there (measured on the
   // Peptides-like config: 279 us resident vs 180 us general for fwd+bwd), so such graphs keep the general kernels.
   if ((long)nnz < (long)kBlockMinAvgDegree * m) return false;
-  p = Plan{plan_dev, meta[0], meta[1], meta[2], meta[3], m, nnz, f, meta[8], meta[9]};
+  p = Plan{plan_dev, meta[0], meta[1], meta[2], meta[3], m, nnz, f, meta[8], meta[9], meta[10]};
   return true;
 }
 
@@ -136,6 +136,34 @@ int dfgnn_gt_tiling_fwd(int m, int nnz, int h, int f, const int *row_ptr, const 
   if (!Q || !K || !V || !out) return kErrBadArg;
   const Csr g{m, nnz, h, f, row_ptr, col_ind, nullptr, val};
   return launch_gt_tiling_fwd(g, Q, K, V, out, as_stream(stream));
+}
+
+static int gt_csr_impl(bool use_lds, int m, int nnz, int h, int f, const int *row_ptr, const int *col_ind, const float *val,
+                       const float *Q, const float *K, const float *V, float *logits, float *out, dfgnn_stream_t stream) {
+  if (int c = check_common(m, nnz, h, f, row_ptr, col_ind)) return c < 0 ? c : 0;
+  if (!Q || !K || !V || !out || (nnz > 0 && !logits)) return kErrBadArg;
+  const Csr g{m, nnz, h, f, row_ptr, col_ind, nullptr, val};
+  return launch_gt_csr_fwd(g, Q, K, V, logits, out, use_lds, as_stream(stream));
+}
+
+int dfgnn_gt_csr_fwd(int m, int nnz, int h, int f, const int *row_ptr, const int *col_ind, const float *val,
+                     const float *Q, const float *K, const float *V, float *logits, float *out, dfgnn_stream_t stream) {
+  return gt_csr_impl(true, m, nnz, h, f, row_ptr, col_ind, val, Q, K, V, logits, out, stream);
+}
+
+int dfgnn_gt_csr_gm_fwd(int m, int nnz, int h, int f, const int *row_ptr, const int *col_ind, const float *val,
+                        const float *Q, const float *K, const float *V, float *logits, float *out,
+                        dfgnn_stream_t stream) {
+  return gt_csr_impl(false, m, nnz, h, f, row_ptr, col_ind, val, Q, K, V, logits, out, stream);
+}
+
+int dfgnn_gat_recompute_fwd(int m, int nnz, int h, int f, const int *row_ptr, const int *col_ind, const float *attn_row,
+                            const float *attn_col, float negative_slope, const float *X, float *out,
+                            dfgnn_stream_t stream) {
+  if (int c = check_common(m, nnz, h, f, row_ptr, col_ind)) return c < 0 ? c : 0;
+  if (!attn_row || !attn_col || !X || !out) return kErrBadArg;
+  const Csr g{m, nnz, h, f, row_ptr, col_ind, nullptr, nullptr};
+  return launch_gat_recompute_fwd(g, attn_row, attn_col, negative_slope, X, out, as_stream(stream));
 }
 
 static int gt_softmax_impl(bool use_lds, int m, int nnz, int h, int f, const int *row_ptr, const int *col_ind,

@@ -1,0 +1,302 @@
+// dfgnn_dense_lean.hpp -- matrix-core GT forward for dense ranges of <= 128 nodes, TWO workgroups per CU.
+//
+// The 512-thread forward (gt_dense.hip: dense_fwd_body) owns a CU: 8 waves x up to 256 VGPRs and ~115 KB of LDS.  Its
+// phases alternate between moving bytes (prologue: edges + K + Q; V image) and computing (S, softmax, P V), and a CU
+// streams from HBM at most its share of the chip's rate (~10 B / cycle: tools/diag/stream_probe.hip reaches 6.2 TB/s
+// only with every CU loading ALL the time), so the memory pipe of a CU idles while its one workgroup computes: the
+// forward runs at ~55 % of the streaming rate.  This body is sized so that TWO workgroups fit a CU -- 256 threads
+// (4 waves, each owning strips w and w + 4), <= 256 VGPRs, < 80 KB of LDS -- and the hardware overlaps one workgroup's
+// loads with the other's matrix / vector phases:
+//   * feature matrices are staged 64 columns at a time (40 KB image): S accumulates over the two K halves, the two V
+//     halves give the two halves of the output row;
+//   * the next half image travels in registers while the current one is used (as in the 512-thread kernels).
+// Same numerics and layouts as dfgnn_dense.hpp (fp16 hi / lo operand halves under power-of-two scales).
+// Replaces, for such ranges, the same reference kernels as gt_dense.hip (fused_gtconv_hyper.cu:165-532).
+#pragma once
+#include "dfgnn_dense.hpp"
+
+namespace dfgnn {
+
+constexpr int kLeanThreads = 256;
+constexpr int kLeanWaves = kLeanThreads / kWave;
+constexpr int kLeanLdsBytes = 80 * 1024;
+
+template <int F, bool WRITE_ATTN>
+__global__ __launch_bounds__(kLeanThreads, 2) void gt_dense_fwd_lean_kernel(Csr g, const int *__restrict__ fit,
+                                                                           const float *__restrict__ Q,
+                                                                           const float *__restrict__ K,
+                                                                           const float *__restrict__ V,
+                                                                           float *__restrict__ attn_edge,
+                                                                           float *__restrict__ out) {
+  static_assert(F == 64 || F == 128, "lean forward: whole 64-column halves only");
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int FW = 64, NH = F / FW, NP = 128, NT = NP / 16, NS = 2, PRE = 16;
+  using D = DenseCfg<FW>;
+  constexpr int RS = D::RS, KT = D::KT, FT = D::FT, MS = NP + 4;
+  constexpr int PER = NP * (FW / 8) / kLeanThreads;  // 8-float pieces of an image per thread (4)
+  const int n0 = fit[2 * blockIdx.x], n1 = fit[2 * blockIdx.x + 1] & kPlanRangeMask;
+  const int n = n1 - n0, e0 = g.row_ptr[n0], ne = g.row_ptr[n1] - e0, head = blockIdx.y;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+  const int npad = (n + 31) & ~31, ntile = npad >> 4, nstrip = (n + 15) >> 4;
+  h16 *ihi = reinterpret_cast<h16 *>(lds), *ilo = ihi + NP * RS;
+  unsigned char *map = reinterpret_cast<unsigned char *>(ilo + NP * RS);
+  const int map_bytes = nstrip * 16 * MS;
+  int *rp = reinterpret_cast<int *>(map + ((map_bytes + 15) & ~15));
+  float *smax = reinterpret_cast<float *>(rp + ((n + 4) & ~3));  // [4] per-wave maxima of the image being staged
+  float *pstage = smax + 4;                                       // [ne] normalised attention values, if it fits
+  const size_t fixed_bytes = (size_t)(reinterpret_cast<char *>(pstage) - reinterpret_cast<char *>(lds));
+  const bool stage_attn = WRITE_ATTN && fixed_bytes + (size_t)ne * 4 <= (size_t)kLeanLdsBytes;
+  const size_t hf = (size_t)g.h * F, hoff = (size_t)head * F;
+  const float *Qb = Q + (size_t)n0 * hf + hoff, *Kb = K + (size_t)n0 * hf + hoff, *Vb = V + (size_t)n0 * hf + hoff;
+  float *Ob = out + (size_t)n0 * hf + hoff;
+
+  // ---- half images through registers ---------------------------------------------------------------------------------
+  float4 ia[PER], ib[PER];
+  auto image_fetch = [&](const float *src) {  // rows 0 .. n-1 (clamped), 64 columns starting at src
+    const int tid = opaque_tid();
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      const int idx = tid + k * kLeanThreads;
+      const unsigned off = (unsigned)min(idx >> 3, n - 1) * (unsigned)hf + 8u * (idx & 7);
+      ia[k] = ld32_f4(src, off);
+      ib[k] = ld32_f4(src, off + 4);
+    }
+  };
+  auto image_post = [&]() {
+    float mx = 0.f;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) mx = fmaxf(mx, absmax8(ia[k], ib[k]));
+    mx = wave_max(mx);
+    if ((threadIdx.x & (kWave - 1)) == 0) smax[wave] = mx;
+  };
+  Pow2Scale isc{1.f, 1.f};
+  auto image_store = [&]() {
+    const float4 w = *reinterpret_cast<const float4 *>(smax);
+    isc = pow2_scale(fmaxf(fmaxf(w.x, w.y), fmaxf(w.z, w.w)));
+    const int tid = opaque_tid();
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      const int idx = tid + k * kLeanThreads, row = idx >> 3, c8 = idx & 7;
+      const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+      hx8 hh, ll;
+      split_hx8(row < n ? ia[k] : z, row < n ? ib[k] : z, isc.s, hh, ll);
+      *reinterpret_cast<hx8 *>(ihi + row * RS + 8 * c8) = hh;
+      *reinterpret_cast<hx8 *>(ilo + row * RS + 8 * c8) = ll;
+    }
+    asm volatile("" ::: "memory");
+  };
+  // this wave's Q rows, one feature half: raw, then fp16 operand fragments under a per-strip scale
+  float4 qa[NS][KT], qb[NS][KT];
+  auto q_fetch = [&](int h) {
+    const LaneIds L = lane_ids();
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const unsigned off = (unsigned)min((wave + kLeanWaves * s) * 16 + L.mi, n - 1) * (unsigned)hf + (unsigned)(h * FW) + 8u * L.mq;
+#pragma unroll
+      for (int t = 0; t < KT; ++t) {
+        qa[s][t] = ld32_f4(Qb, off + 32 * t);
+        qb[s][t] = ld32_f4(Qb, off + 32 * t + 4);
+      }
+    }
+  };
+  hx8 qh[NS][KT], ql[NS][KT];
+  float qinv[NS];
+  auto q_convert = [&]() {
+    const LaneIds L = lane_ids();
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const bool valid = (wave + kLeanWaves * s) * 16 + L.mi < n;
+      float qm = 0.f;
+#pragma unroll
+      for (int t = 0; t < KT; ++t) {
+        if (!valid) qa[s][t] = qb[s][t] = make_float4(0.f, 0.f, 0.f, 0.f);
+        qm = fmaxf(qm, absmax8(qa[s][t], qb[s][t]));
+      }
+      const Pow2Scale qs = pow2_scale(wave_max(qm));
+      qinv[s] = qs.inv;
+#pragma unroll
+      for (int t = 0; t < KT; ++t) split_hx8(qa[s][t], qb[s][t], qs.s, qh[s][t], ql[s][t]);
+    }
+  };
+
+  // ---- prologue: everything that is needed first is requested first ------------------------------------------------
+  int rp_mine = 0;
+  {
+    const int tid = opaque_tid();
+    if (tid <= n) rp_mine = g.row_ptr[n0 + tid];
+  }
+  int pre_i[PRE], pre_j[PRE];
+  {
+    const int tid = opaque_tid();
+#pragma unroll
+    for (int k = 0; k < PRE; ++k) {
+      const unsigned e = (unsigned)min(tid + k * kLeanThreads, ne - 1);
+      pre_i[k] = ld32(g.rows + e0, e);
+      pre_j[k] = ld32(g.col_ind + e0, e);
+    }
+  }
+  image_fetch(Kb);
+  q_fetch(0);
+  {
+    const int tid = opaque_tid();
+    for (int k = tid; k < (map_bytes >> 2); k += kLeanThreads) reinterpret_cast<unsigned *>(map)[k] = 0xFFFFFFFFu;
+    if (tid <= n) rp[tid] = rp_mine - e0;
+  }
+  lds_barrier();
+  {  // byte map: position of every edge within its row (0xFF: no edge)
+    const int tid = opaque_tid();
+#pragma unroll
+    for (int k = 0; k < PRE; ++k) {
+      const int e = tid + k * kLeanThreads;
+      if (e < ne) {
+        const int i = pre_i[k] - n0, j = pre_j[k] - n0;
+        map[i * MS + j] = (unsigned char)(e - rp[i]);
+      }
+    }
+    constexpr int B = 8;
+    for (int base = PRE * kLeanThreads; base < ne; base += B * kLeanThreads) {
+      int bi[B], bj[B];
+#pragma unroll
+      for (int k = 0; k < B; ++k) {
+        const unsigned e = (unsigned)min(base + tid + k * kLeanThreads, ne - 1);
+        bi[k] = ld32(g.rows + e0, e);
+        bj[k] = ld32(g.col_ind + e0, e);
+      }
+#pragma unroll
+      for (int k = 0; k < B; ++k) {
+        const int e = base + tid + k * kLeanThreads;
+        if (e < ne) map[(bi[k] - n0) * MS + (bj[k] - n0)] = (unsigned char)(e - rp[bi[k] - n0]);
+      }
+    }
+  }
+  image_post();
+  lds_barrier();
+  image_store();  // K, half 0
+  q_convert();
+  lds_barrier();
+
+  // ---- S = Q K^T, accumulated over the feature halves ---------------------------------------------------------------
+  f32x4 S[NS][NT];
+#pragma unroll
+  for (int s = 0; s < NS; ++s)
+#pragma unroll
+    for (int u = 0; u < NT; ++u) S[s][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int h = 0; h < NH; ++h) {
+    if (h + 1 < NH) {
+      image_fetch(Kb + (h + 1) * FW);
+      q_fetch(h + 1);
+    } else {
+      image_fetch(Vb);
+    }
+    {
+      const LaneIds L = lane_ids();
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        if (wave + kLeanWaves * s < nstrip) {
+          const float c = isc.inv * qinv[s];
+#pragma unroll
+          for (int u = 0; u < NT; ++u)
+            if (u < ntile) S[s][u] += dense_rows_mma<FW>(ihi, ilo, u, qh[s], ql[s], L) * c;
+        }
+      }
+    }
+    if (h + 1 < NH) {
+      image_post();
+      lds_barrier();
+      image_store();  // K, half h + 1
+      q_convert();
+      lds_barrier();
+    }
+  }
+
+  // ---- masked row softmax, in registers ------------------------------------------------------------------------------
+  float inv[NS];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    inv[s] = 0.f;
+    const int strip = wave + kLeanWaves * s;
+    if (strip < nstrip) {
+      const LaneIds L = lane_ids();
+      const int i = strip * 16 + L.mi;
+      const unsigned char *mrow = map + i * MS + 4 * L.mq;
+      float mx = -INFINITY;
+#pragma unroll
+      for (int jt = 0; jt < NT; ++jt) {
+        const unsigned w = (jt < ntile) ? *reinterpret_cast<const unsigned *>(mrow + 16 * jt) : 0xFFFFFFFFu;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const bool edge = ((w >> (8 * r)) & 0xFFu) != 0xFFu;
+          const float x = edge ? S[s][jt][r] : -INFINITY;
+          S[s][jt][r] = x;
+          mx = fmaxf(mx, x);
+        }
+      }
+      mx = xor16_32_max(mx);
+      const float base = (mx == -INFINITY) ? 0.f : mx;
+      float sum = 0.f;
+#pragma unroll
+      for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float p = fast_exp(S[s][jt][r] - base);  // exp(-inf) = 0 for the masked pairs
+          S[s][jt][r] = p;
+          sum += p;
+        }
+      sum = xor16_32_sum(sum);
+      inv[s] = (sum != 0.f) ? 1.f / sum : 0.f;
+      if constexpr (WRITE_ATTN) {
+        if (i < n) {
+          float *lrow = pstage + rp[i];
+          float *grow = attn_edge + (size_t)head * g.nnz + e0 + rp[i];
+#pragma unroll
+          for (int jt = 0; jt < NT; ++jt) {
+            if (jt < ntile) {
+              const unsigned w = *reinterpret_cast<const unsigned *>(mrow + 16 * jt);
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const unsigned slot = (w >> (8 * r)) & 0xFFu;
+                if (slot != 0xFFu) {
+                  if (stage_attn) lrow[slot] = S[s][jt][r] * inv[s];
+                  else grow[slot] = S[s][jt][r] * inv[s];
+                }
+              }
+            }
+          }
+        }
+        if (stage_attn) {  // the strip streams its own contiguous slice of attn_edge out
+          wave_sync();
+          const int s0 = rp[strip * 16], s1 = rp[min(n, strip * 16 + 16)];
+          float *dst = attn_edge + (size_t)head * g.nnz + e0;
+          for (int e = s0 + (int)(threadIdx.x & (kWave - 1)); e < s1; e += kWave) dst[e] = pstage[e];
+        }
+      }
+    }
+  }
+
+  // ---- O = P V, one feature half at a time ---------------------------------------------------------------------------
+#pragma unroll
+  for (int h = 0; h < NH; ++h) {
+    image_post();
+    lds_barrier();  // every strip is done with the previous image
+    image_store();  // V, half h
+    if (h + 1 < NH) image_fetch(Vb + (h + 1) * FW);
+    lds_barrier();
+    const LaneIds L = lane_ids();
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const int strip = wave + kLeanWaves * s;
+      if (strip < nstrip) {
+        f32x4 o[FT];
+#pragma unroll
+        for (int ft = 0; ft < FT; ++ft) o[ft] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int jb = 0; jb < NP / 32; ++jb)
+          if (2 * jb < ntile) dense_cols_mma<FW, 4>(o, ihi, ilo, jb, S[s][2 * jb], S[s][2 * jb + 1], kUnitScale, L);
+        dense_store_rows<FT>(o, inv[s] * (isc.inv * kUnitScaleInv), Ob + h * FW, (unsigned)hf, strip * 16 + L.mi, n, L);
+      }
+    }
+  }
+}
+
+}  // namespace dfgnn

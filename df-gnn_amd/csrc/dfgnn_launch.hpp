@@ -45,6 +45,7 @@ struct Plan {              // host view of a built plan (see plan.hip for the de
   const int *dev;          // device buffer, may be null (= no plan: general kernels only)
   int num_fit, num_spill, max_fit_nodes, max_fit_edges, m, nnz, f, num_edge_global;
   int num_dense;           // the first num_dense fit ranges carry kPlanDense (gt_dense.hip)
+  int num_dense_wide = 0;  // ... and the first num_dense_wide of those have more than 128 nodes
   const int *fit() const { return dev + kPlanHeader; }
   const int *spill() const { return dev + kPlanHeader + 2 * (size_t)m; }
 };
@@ -106,6 +107,11 @@ int launch_gat_dense_bwd(const Csr &g, const Plan &p, const float *attn_row, con
 int launch_gt_tiling_fwd(const Csr &g, const float *Q, const float *K, const float *V, float *out,
                          hipStream_t s);
 int launch_gt_sddmm(const Csr &g, const float *Q, const float *K, float *logits, hipStream_t s);
+// node-parallel CSR baselines (csr_fwd.hip): 'csr' (row logits in LDS) / 'csr_gm' (in global memory), GAT 'hyper_recompute'
+int launch_gt_csr_fwd(const Csr &g, const float *Q, const float *K, const float *V, float *logits, float *out,
+                      bool use_lds, hipStream_t s);
+int launch_gat_recompute_fwd(const Csr &g, const float *attn_row, const float *attn_col, float slope, const float *X,
+                             float *out, hipStream_t s);
 int launch_softmax_spmm(const Csr &g, const float *logits, const float *X, float *out, bool use_lds,
                         hipStream_t s);
 int launch_gt_bwd_rows(const Csr &g, const float *K, const float *V, const float *attn_edge,

@@ -47,6 +47,7 @@ __device__ unsigned long long *dfgnn_dense_stamps = nullptr;  // [wg][16] phase 
 #define DFGNN_RING160 2  // prefetch distance (image phases) of the 129..160-node backward
 #endif
 #include "dfgnn_dense_wide.hpp"
+#include "dfgnn_dense_lean.hpp"
 namespace dfgnn {
 
 // =====================================================================================================================
@@ -1008,18 +1009,46 @@ static int dispatch_dense(int f, Fn &&fn) {
   return kErrUnsupported;
 }
 
+// DFGNN_LEAN=0 in the environment (diagnostic switch, read once): every dense range on the 512-thread forward
+static bool lean_enabled() {
+  static const bool on = [] { const char *e = getenv("DFGNN_LEAN"); return !e || atoi(e) != 0; }();
+  return on;
+}
+
 int launch_gt_dense_fwd(const Csr &g, const Plan &p, const float *Q, const float *K, const float *V,
                         float *attn_edge, float *out, hipStream_t s) {
   if (p.num_dense == 0) return 0;
-  const dim3 grid(p.num_dense, g.h);
+  // the ranges of more than 128 nodes come first in the list and take the 512-thread kernel (one workgroup per CU);
+  // the others -- for the widths it is built for -- the 256-thread kernel, two workgroups per CU (dfgnn_dense_lean.hpp)
+  // -- when there are none of the former: two launches would serialise (the second waits for the first one's tail), which
+  // costs a mixed batch more than the second kernel gains
+  const int nlean = ((g.f == 64 || g.f == 128) && lean_enabled() && p.num_dense_wide == 0) ? p.num_dense : 0;
+  const int nbig = p.num_dense - nlean;
   return dispatch_dense(g.f, [&](auto fc) {
     constexpr int F = decltype(fc)::value;
-    if (attn_edge) {
-      if (int rc = set_max_lds(gt_dense_fwd_kernel<F, true>)) return rc;
-      gt_dense_fwd_kernel<F, true><<<grid, kDenseThreads, kLdsBytes, s>>>(g, p.fit(), Q, K, V, attn_edge, out, kLdsBytes);
-    } else {
-      if (int rc = set_max_lds(gt_dense_fwd_kernel<F, false>)) return rc;
-      gt_dense_fwd_kernel<F, false><<<grid, kDenseThreads, kLdsBytes, s>>>(g, p.fit(), Q, K, V, nullptr, out, kLdsBytes);
+    if (nbig > 0) {
+      const dim3 grid(nbig, g.h);
+      if (attn_edge) {
+        if (int rc = set_max_lds(gt_dense_fwd_kernel<F, true>)) return rc;
+        gt_dense_fwd_kernel<F, true><<<grid, kDenseThreads, kLdsBytes, s>>>(g, p.fit(), Q, K, V, attn_edge, out, kLdsBytes);
+      } else {
+        if (int rc = set_max_lds(gt_dense_fwd_kernel<F, false>)) return rc;
+        gt_dense_fwd_kernel<F, false><<<grid, kDenseThreads, kLdsBytes, s>>>(g, p.fit(), Q, K, V, nullptr, out, kLdsBytes);
+      }
+      if (int rc = launch_status()) return rc;
+    }
+    if constexpr (F == 64 || F == 128) {
+      if (nlean > 0) {
+        const dim3 grid(nlean, g.h);
+        const int *fit = p.fit() + 2 * (size_t)nbig;
+        if (attn_edge) {
+          if (int rc = set_max_lds(gt_dense_fwd_lean_kernel<F, true>)) return rc;
+          gt_dense_fwd_lean_kernel<F, true><<<grid, kLeanThreads, kLeanLdsBytes, s>>>(g, fit, Q, K, V, attn_edge, out);
+        } else {
+          if (int rc = set_max_lds(gt_dense_fwd_lean_kernel<F, false>)) return rc;
+          gt_dense_fwd_lean_kernel<F, false><<<grid, kLeanThreads, kLeanLdsBytes, s>>>(g, fit, Q, K, V, nullptr, out);
+        }
+      }
     }
     return launch_status();
   });

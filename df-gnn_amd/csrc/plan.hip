@@ -143,7 +143,7 @@ __global__ __launch_bounds__(kPlanThreads) void plan_cut_kernel(int m, int nnz, 
   int *s_tot = s_next + kPlanCache;         // [2][kPlanThreads] scan scratch
   unsigned char *s_cls = reinterpret_cast<unsigned char *>(s_tot + 2 * kPlanThreads);  // [kPlanCache]
   unsigned char *s_start = s_cls + kPlanCache;                                          // [kPlanCache]
-  __shared__ int s_nfit, s_stat[4];
+  __shared__ int s_nfit, s_stat[5];
   int *hdr = plan;
   int *fit = plan + kPlanHeader;
   int *spill = fit + 2 * (size_t)m;
@@ -164,7 +164,7 @@ __global__ __launch_bounds__(kPlanThreads) void plan_cut_kernel(int m, int nnz, 
 
   const int nb = *count;
   if (nb <= kPlanCache) {
-    if (t < 4) s_stat[t] = 0;
+    if (t < 5) s_stat[t] = 0;
     for (int k = t; k <= nb; k += kPlanThreads) {
       const int en = k ? bounds[k - 1] : 0;
       s_end[k] = en;
@@ -233,6 +233,7 @@ __global__ __launch_bounds__(kPlanThreads) void plan_cut_kernel(int m, int nnz, 
           atomicMax(&s_stat[1], ed);
           if (flags & kPlanEdgeGlobal) atomicAdd(&s_stat[2], 1);
           if (flags & kPlanDense) atomicAdd(&s_stat[3], 1);
+          if ((flags & kPlanDense) && s_end[j] - s_end[k] > 128) atomicAdd(&s_stat[4], 1);
         }
       }
     }
@@ -249,17 +250,19 @@ __global__ __launch_bounds__(kPlanThreads) void plan_cut_kernel(int m, int nnz, 
       hdr[7] = budget_bytes;
       hdr[8] = s_stat[2];
       hdr[9] = s_stat[3];
-      hdr[10] = hdr[11] = 0;
+      hdr[10] = s_stat[4];  // dense ranges of more than 128 nodes: they come first in the sorted list
+      hdr[11] = 0;
       s_nfit = nfit;
     }
   } else if (t == 0) {
     // serial walk over the global arrays (long lists of natural ranges: batches of thousands of tiny graphs)
-    int nfit = 0, nspill = 0, maxn = 0, maxe = 0, nglobal = 0, ndense = 0;
+    int nfit = 0, nspill = 0, maxn = 0, maxe = 0, nglobal = 0, ndense = 0, nwide = 0;
     auto flush = [&](int n0, int n1, int ed, int bad0, int bad1) {
       if (n1 <= n0) return;
       const int flags = fit_entry(nfit, n0, n1, ed, bad0, bad1);
       nglobal += (flags & kPlanEdgeGlobal) ? 1 : 0;
       ndense += (flags & kPlanDense) ? 1 : 0;
+      nwide += ((flags & kPlanDense) && n1 - n0 > 128) ? 1 : 0;
       ++nfit;
       maxn = max(maxn, n1 - n0);
       maxe = max(maxe, ed);
@@ -316,7 +319,8 @@ __global__ __launch_bounds__(kPlanThreads) void plan_cut_kernel(int m, int nnz, 
     hdr[7] = budget_bytes;
     hdr[8] = nglobal;
     hdr[9] = (nfit <= kPlanCache) ? ndense : 0;  // the dense ranges are only usable once sorted to the front (below)
-    hdr[10] = hdr[11] = 0;
+    hdr[10] = (nfit <= kPlanCache) ? nwide : 0;
+    hdr[11] = 0;
     s_nfit = nfit;
   }
   __syncthreads();

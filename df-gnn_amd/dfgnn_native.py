@@ -23,6 +23,9 @@ SIGNATURES = {
     "dfgnn_gt_bwd_rows": [_i, _i, _i, _i] + [_vp] * 11,
     "dfgnn_gt_bwd_cols": [_i, _i, _i, _i] + [_vp] * 11,
     "dfgnn_gt_tiling_fwd": [_i, _i, _i, _i] + [_vp] * 8,
+    "dfgnn_gt_csr_fwd": [_i, _i, _i, _i] + [_vp] * 9,
+    "dfgnn_gt_csr_gm_fwd": [_i, _i, _i, _i] + [_vp] * 9,
+    "dfgnn_gat_recompute_fwd": [_i, _i, _i, _i] + [_vp] * 4 + [_f] + [_vp] * 3,
     "dfgnn_gt_softmax_fwd": [_i, _i, _i, _i] + [_vp] * 10,
     "dfgnn_gt_softmax_gm_fwd": [_i, _i, _i, _i] + [_vp] * 10,
     "dfgnn_gat_hyper_fwd": [_i, _i, _i, _i] + [_vp] * 5 + [_f] + [_vp] * 6,

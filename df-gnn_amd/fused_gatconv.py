@@ -112,11 +112,17 @@ def gat_inference(attn_row, attn_col, row_ptr, col_ind, negative_slope, in_feat)
 
 
 def gat_inference_hyper_recompute(attn_row, attn_col, indptr, indices, negative_slope, in_feat):
-    """fused_gatconv.cpp:124-142 -> Tensor.  CSR only; the reference's kernel recomputes the logits instead of keeping
-    them in shared memory (fused_gatconv_hyper_recompute.cu) -- which is what the online-softmax tiling kernel does for
-    every row, so it serves this entry point (same function, no degree limit, any f; the reference exit(0)s unless
-    f % 128 == 0)."""
-    return gat_inference_tiling(attn_row, attn_col, indptr, indices, negative_slope, in_feat)
+    """fused_gatconv.cpp:124-142 -> Tensor.  CSR only; node-parallel, no logit storage: the rank-one logits are recomputed
+    in each of the three sweeps (max, sum, weighted sum), like the reference's kernel
+    (fused_gatconv_hyper_recompute.cu:118-216) -- csrc/csr_fwd.hip:gat_recompute_fwd_kernel; any f (the reference exit(0)s
+    unless f % 128 == 0)."""
+    m, nnz, h, f = _check(attn_row, attn_col, indptr, indices, None, in_feat)
+    with torch.cuda.device(in_feat.device):
+        out = torch.empty_like(in_feat)
+        _n.check(_n.lib().dfgnn_gat_recompute_fwd(m, nnz, h, f, ptr(indptr), ptr(indices), ptr(attn_row), ptr(attn_col),
+                                                  float(negative_slope), ptr(in_feat), ptr(out),
+                                                  stream_ptr(in_feat.device)), "gat_inference_hyper_recompute")
+    return out
 
 
 def gat_inference_hyper_v2(smem_consume, a_l, a_r, indptr, indices, negative_slope, in_feat):

@@ -151,16 +151,33 @@ def gt_tiling_inference(indptr, indices, val, smem_consume, Q, K, V):
     return [out]
 
 
+def _gt_csr(fn_name, what, indptr, indices, val, Q, K, V):
+    check_device(indptr=indptr, indices=indices, val=val)
+    check_contiguous(indptr=indptr, indices=indices, val=val)
+    check_dtype(torch.int32, indptr=indptr, indices=indices)
+    check_dtype(torch.float32, val=val)
+    _check_qkv(Q, K, V)
+    m, nnz, h, f = _dims(indptr, indices, Q)
+    _check_graph(indptr, indices, Q.size(0))
+    _check_edges(nnz, val=val)
+    with torch.cuda.device(Q.device):
+        out = torch.empty_like(Q)
+        logits = torch.empty((h, nnz), dtype=torch.float32, device=Q.device)
+        _n.check(getattr(_n.lib(), fn_name)(m, nnz, h, f, ptr(indptr), ptr(indices), val_ptr(val), ptr(Q), ptr(K), ptr(V),
+                                            ptr(logits), ptr(out), stream_ptr(Q.device)), what)
+    return [out]
+
+
 def gt_csr_inference(indptr, indices, val, smem_consume, Q, K, V):
-    """fused_gtconv.cpp:174-207.  The reference's dgNN-style node-parallel CSR baseline is not one
-    of the three variants in scope; the entry point is kept and served by the
-    CSR-only node-parallel tiling kernel, which computes the same function with no degree limit."""
-    return gt_tiling_inference(indptr, indices, val, smem_consume, Q, K, V)
+    """fused_gtconv.cpp:174-207 -> [out].  The node-parallel CSR baseline of the reference's sweeps (fused_gt_csr): a wave
+    per row, the row's logits materialised in LDS (csrc/csr_fwd.hip), then max / sum / weighted-sum sweeps."""
+    return _gt_csr("dfgnn_gt_csr_fwd", "gt_csr_inference", indptr, indices, val, Q, K, V)
 
 
 def gt_csr_gm_inference(indptr, indices, val, Q, K, V):
-    """fused_gtconv.cpp:209-242 (see gt_csr_inference)."""
-    return gt_tiling_inference(indptr, indices, val, 0, Q, K, V)
+    """fused_gtconv.cpp:209-242 -> [out].  As gt_csr_inference with the logits in global memory
+    (fused_gt_csr_global_memory)."""
+    return _gt_csr("dfgnn_gt_csr_gm_fwd", "gt_csr_gm_inference", indptr, indices, val, Q, K, V)
 
 
 def _gt_softmax(fn_name, what, indptr, indices, rows, val, Q, K, V):

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define DFGNN_ABI_VERSION 6
+#define DFGNN_ABI_VERSION 7
 
 #define DFGNN_E_BADARG (-1)      /* negative size / NULL required pointer                      */
 #define DFGNN_E_UNSUPPORTED (-2) /* feature width outside the compiled range (f > 1024, or     */
@@ -154,6 +154,24 @@ int dfgnn_gat_hyper_fwd(int m, int nnz, int h, int f, const int *row_ptr, const 
                         const int *rows, const float *attn_row, const float *attn_col,
                         float negative_slope, const float *X, float *edge_ws, float *out,
                         const int *plan, const int *plan_meta, dfgnn_stream_t stream);
+
+/* replaces gt_csr_inference / gt_csr_gm_inference (fused_gtconv.cpp:174-242; fused_gt_csr,
+ * fused_gt_csr_global_memory, fused_gtconv_csr.cu:10-219): the node-parallel CSR baselines of the reference's sweeps --
+ * a wave per row, the row's logits materialised (in LDS: 'csr', rows longer than the 2048-float buffer use `logits`;
+ * in global memory: 'csr_gm'), then max / sum / weighted-sum sweeps.  logits: fp32[h, nnz] scratch. */
+int dfgnn_gt_csr_fwd(int m, int nnz, int h, int f, const int *row_ptr, const int *col_ind, const float *val,
+                     const float *Q, const float *K, const float *V, float *logits, float *out,
+                     dfgnn_stream_t stream);
+int dfgnn_gt_csr_gm_fwd(int m, int nnz, int h, int f, const int *row_ptr, const int *col_ind, const float *val,
+                        const float *Q, const float *K, const float *V, float *logits, float *out,
+                        dfgnn_stream_t stream);
+
+/* replaces gat_inference_hyper_recompute (fused_gatconv.cpp:124-142; fused_gat_hyper_recompute_inference_vec4,
+ * fused_gatconv_hyper_recompute.cu:118-216): node-parallel, no logit storage -- the rank-one logits are recomputed in
+ * each of the three sweeps.  Any f (the reference exit(0)s unless f % 128 == 0). */
+int dfgnn_gat_recompute_fwd(int m, int nnz, int h, int f, const int *row_ptr, const int *col_ind,
+                            const float *attn_row, const float *attn_col, float negative_slope, const float *X,
+                            float *out, dfgnn_stream_t stream);
 
 /* replaces gat_inference_softmax (fused_gatconv.cpp:40-61, fused_gatconv_softmax.cu:33-56) and
  * gat_inference_softmax_gm (fused_gatconv.cpp:69-90, fused_gatconv_softmax_gm.cu) */

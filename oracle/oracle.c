@@ -12,7 +12,8 @@
  * (no nvcc / NVIDIA GPU here).  This restatement is therefore anchored on the
  * reference's call sites and kernel semantics cited below, and is cross-checked
  * in tests/ against a second, independently written dense-masked numpy/torch
- * restatement (oracle/dense_ref.py) and hand-derived known-answer cases.
+ * restatement (oracle/dense_ref.py), an edge-list torch / autograd one
+ * (oracle/torch_ref.py) and hand-derived known-answer cases.
  *
  * Math (reference files are cited relative to /root/reference):
  *   GT  logit  s_e = val_e * <Q[i,h,:], K[j,h,:]>          DFGNN/layers/GT/gtconv_layer.py:29-31

@@ -53,6 +53,7 @@ def _gt_all_variants(g, check_attn=True):
     errs["softmax"] = _close(ops.GTConvFuse_inference_softmax(ip, idx, rows, val, 128, Q, K, V), g["out"], "softmax")
     errs["softmax_gm"] = _close(ops.GTConvFuse_inference_softmax_gm(ip, idx, rows, val, Q, K, V), g["out"], "gm")
     errs["csr"] = _close(ops.GTConvFuse_inference_csr(ip, idx, val, 128, Q, K, V), g["out"], "csr")
+    errs["csr_gm"] = _close(gt.gt_csr_gm_inference(ip, idx, val, Q, K, V)[0], g["out"], "csr_gm")
     cp, ri, vi = _t(g["col_ptr"]), _t(g["row_ind"]), _t(g["val_idx"])
     out, attn = gt.gt_hyper_forward(ip, idx, rows, val, cp, ri, vi, 1024, Q, K, V)
     errs["fwd_train"] = _close(out, g["out"], "hyper_forward out")
@@ -365,9 +366,11 @@ def test_layers_fused_vs_baseline():
     torch.manual_seed(0)
     g = S.pattern_like(batch_size=16, seed=3).to(DEV)
     x = torch.randn(g.num_nodes(), 64, device=DEV)
-    for conv in ("gt", "gat", "agnn"):
+    for conv in ("gt", "gat", "agnn", "dotgat"):
         for fmt in ("hyper", "softmax", "softmax_gm", "tiling", "csr", "csr_gm", "hyper_ablation", "hyper_v2",
                     "hyper_recompute"):
+            if conv == "dotgat" and fmt not in ("hyper", "csr", "softmax"):
+                continue                                    # the reference's DOTGAT layer classes (layers/GAT_DOT)
             if conv != "gat" and fmt in ("hyper_v2", "hyper_recompute"):
                 continue                                    # GAT-only variants (reference layers/util.py:403-406)
             if (conv == "agnn" and fmt == "hyper_ablation") or (conv == "gat" and fmt == "csr_gm"):
@@ -376,8 +379,13 @@ def test_layers_fused_vs_baseline():
             torch.manual_seed(sum(map(ord, conv + fmt)))    # weights do not depend on the order of this loop
             layer = load_graphconv_layer(args).to(DEV).eval()
             with torch.no_grad():
-                base, _ = layer(preprocess_dglsp(g), x, fuse=False)
-                fused, ms = layer(load_prepfunc(args)(g), x, fuse=True)
+                if conv == "dotgat":                        # params carry the graph itself for the non-fused branch
+                    params = load_prepfunc(args)(g)
+                    base, _ = layer(params, x * 0.2, fuse=False)
+                    fused, ms = layer(params, x * 0.2, fuse=True)
+                else:
+                    base, _ = layer(preprocess_dglsp(g), x, fuse=False)
+                    fused, ms = layer(load_prepfunc(args)(g), x, fuse=True)
             assert torch.allclose(base, fused, atol=1e-4, rtol=1e-3), (conv, fmt)
             ok = check_correct(base[:1000], fused[:1000]) and check_correct(base[-1000:], fused[-1000:])
             assert ok, (conv, fmt)

@@ -203,3 +203,35 @@ def test_check_correct_follows_the_reference_rule(capsys):
     d[2, 2] = -2e-6                                  # near-zero elements: relative check trips, absolute error tiny
     assert not check_correct(c, d)
     assert "error node 2 mismatch" in capsys.readouterr().out
+
+
+def test_dotgat_baseline_restates_dgl_dotgatconv():
+    """DotGatConv (the torch restatement of dgl.nn.DotGatConv behind the DOTGAT layers' non-fused branch) against a
+    per-node loop of the published algorithm: e_uv = <h_u, h_v>, softmax over the edges arriving at v, sum of a_uv h_u;
+    on a symmetric graph it equals the GT oracle with Q = K = V = H (what the fused branch computes)."""
+    import oracle
+    from DFGNN.layers.GAT_DOT import DotGatConv
+    from DFGNN.layers.util import preprocess_CSR
+    from DFGNN.utils import synthetic as S
+    torch.manual_seed(0)
+    g = S.pattern_like(batch_size=3, seed=4)
+    conv = DotGatConv(12, 5, 2)
+    x = torch.randn(g.num_nodes(), 12) * 0.3
+    with torch.no_grad():
+        out = conv(g, x)
+        h = conv.fc(x).view(-1, 2, 5)
+    src, dst = g.edges()
+    want = torch.zeros_like(out)
+    for v in range(g.num_nodes()):
+        us = src[dst == v]
+        if len(us) == 0:
+            continue
+        for hd in range(2):
+            e = (h[us, hd] * h[v, hd]).sum(-1)
+            a = torch.softmax(e, 0)
+            want[v, hd] = (a[:, None] * h[us, hd]).sum(0)
+    assert torch.allclose(out, want, atol=1e-5)
+    row_ptr, col_ind, val, _ = preprocess_CSR(g)
+    hn = h.numpy()
+    ref = oracle.gt_forward(row_ptr.numpy(), col_ind.numpy(), val.numpy(), hn, hn, hn)
+    assert np.abs(out.numpy() - ref).max() < 1e-5

@@ -46,6 +46,26 @@ def test_c_oracle_vs_torch_restatement(oracle_mod, m, avg, h, f, kw):
     np.testing.assert_allclose(out32, out, rtol=0, atol=1e-3)
 
 
+@pytest.mark.parametrize("m,avg,h,f,kw", [(40, 6, 2, 16, dict(empty_frac=0.2)), (64, 10, 1, 32, dict(dup_frac=0.25)),
+                                         (33, 4, 3, 7, {})])
+def test_c_oracle_vs_dense_masked_restatement(oracle_mod, m, avg, h, f, kw):
+    """Third restatement (oracle/dense_ref.py: masked dense attention, closed-form softmax Jacobian, float64 numpy) --
+    incl. duplicate edges (separate softmax terms) and empty rows."""
+    from oracle import dense_ref
+    rng = np.random.default_rng(7 * m + f)
+    indptr, indices, _ = random_graph(rng, m, avg, **kw)
+    val = np.ones(len(indices), np.float32)
+    Q, K, V, dO = (rng.standard_normal((m, h, f)).astype(np.float32) for _ in range(4))
+    out = oracle_mod.gt_forward(indptr, indices, val, Q, K, V)
+    dQ, dK, dV = oracle_mod.gt_backward(indptr, indices, val, Q, K, V, dO)
+    o3, q3, k3, v3 = dense_ref.gt_forward_backward(indptr, indices, Q, K, V, dO)
+    for a, b in ((out, o3), (dQ, q3), (dK, k3), (dV, v3)):                # (the C oracle hands back fp32 arrays)
+        np.testing.assert_allclose(a, b, rtol=1e-6, atol=1e-7)
+    ar, ac = (rng.standard_normal((m, h)).astype(np.float32) for _ in range(2))
+    np.testing.assert_allclose(oracle_mod.gat_forward(indptr, indices, ar, ac, 0.2, V),
+                               dense_ref.gat_forward(indptr, indices, ar, ac, 0.2, V), rtol=1e-6, atol=1e-7)
+
+
 def test_known_answers(oracle_mod):
     # (1) K == 0 -> uniform attention -> out = mean of neighbour V rows; empty row -> zeros
     indptr = np.array([0, 3, 3, 4], np.int32)

@@ -4,7 +4,13 @@ DFGNN/script/train/train_batch_graph_timing.py:32-53, 146-196): fresh PATTERN-li
 (COO -> CSR / CSC + block plan) paid per batch, L SparseMHA_forward layers sharing the batch structure, MSE loss,
 Adam.  Prints one JSON line per mode (fused operators vs the non-fused torch branch) with the per-step time split the
 reference reports (preprocess / forward / backward+update) and the loss after the last step.
-usage: python3 tools/train_stack.py [--layers 8] [--batch-size 256] [--dim 128] [--steps 12] [--batches 4]"""
+usage: python3 tools/train_stack.py [--layers 8] [--batch-size 256] [--dim 128] [--steps 12] [--batches 4]
+
+Data-parallel form (one process per GPU, `python -m torch.distributed.run --nproc-per-node N tools/train_stack.py
+--modes fused`): every rank trains on its shard of each batch (whole graphs, DFGNN/parallel/sharding.py), the fused
+convolution exchanges nothing, and the weight gradients are all-reduced bucket by bucket while the backward is still
+running (DFGNN/parallel/overlap.py); the line then carries the step time with the exchange overlapped and with it issued
+after the backward.  --dist-backend gloo rehearses it with several ranks on one GPU."""
 import argparse
 import json
 import os
@@ -35,11 +41,21 @@ class Stack(nn.Module):
         return self.out(h)
 
 
-def run(args, fuse, dev):
+def run(args, fuse, dev, overlap=None):
+    import torch.distributed as dist
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
     torch.manual_seed(0)
     model = Stack(args.dim, args.layers).to(dev).train()
     opt = torch.optim.Adam(model.parameters(), lr=1e-3)
-    graphs = [S.pattern_like(batch_size=args.batch_size, seed=10 + b).to(dev) for b in range(args.batches)]
+    sync = None
+    if world > 1:
+        from DFGNN.parallel import OverlappedGradSync, shard_graph
+        sync = OverlappedGradSync(model, overlap=bool(overlap))
+    graphs = [S.pattern_like(batch_size=args.batch_size, seed=10 + b) for b in range(args.batches)]
+    if world > 1:
+        graphs = [shard_graph(g, rank, world)[0] for g in graphs]
+    graphs = [g.to(dev) for g in graphs]
     feats = [torch.randn(g.num_nodes(), args.dim, device=dev, generator=torch.Generator(dev).manual_seed(b))
              for b, g in enumerate(graphs)]
     target = [torch.randn(g.num_nodes(), 1, device=dev, generator=torch.Generator(dev).manual_seed(100 + b))
@@ -61,6 +77,8 @@ def run(args, fuse, dev):
         t2 = time.perf_counter()
         opt.zero_grad(set_to_none=True)
         loss.backward()
+        if sync is not None:
+            sync.finish()
         opt.step()
         torch.cuda.synchronize()
         t3 = time.perf_counter()
@@ -71,7 +89,9 @@ def run(args, fuse, dev):
             edges += g.num_edges() * args.layers
         loss_v = float(loss)
     n = args.steps
-    return {"mode": "fused" if fuse else "torch baseline (fuse=False)", "layers": args.layers, "batch_size": args.batch_size,
+    return {"mode": ("fused" if fuse else "torch baseline (fuse=False)") +
+            ("" if world == 1 else f", {world} ranks, weight-gradient all-reduce " + ("overlapped with the backward" if overlap else "after the backward")),
+            "layers": args.layers, "batch_size": args.batch_size,
             "dim": args.dim, "steps": n, "preprocess_ms": t_prep / n * 1e3, "forward_ms": t_fwd / n * 1e3,
             "backward_update_ms": t_bwd / n * 1e3, "step_ms": (t_prep + t_fwd + t_bwd) / n * 1e3,
             "layer_edges_per_s": edges / (t_prep + t_fwd + t_bwd), "final_loss": loss_v,
@@ -91,8 +111,23 @@ def main():
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--batches", type=int, default=4)
     ap.add_argument("--modes", default="fused,baseline")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"])
     args = ap.parse_args()
-    dev = torch.device("cuda:0")
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0")) % max(1, torch.cuda.device_count())
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(args.dist_backend, **({"device_id": dev} if args.dist_backend == "nccl" else {}))
+        for overlap in (True, False):
+            r = run(args, True, dev, overlap)
+            r.pop("qkv_weights")
+            if dist.get_rank() == 0:
+                print(json.dumps(r), flush=True)
+        dist.destroy_process_group()
+        return
     res = []
     for mode in args.modes.split(","):
         res.append(run(args, mode == "fused", dev))
