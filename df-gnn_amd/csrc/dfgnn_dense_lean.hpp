@@ -249,20 +249,21 @@ __global__ __launch_bounds__(kLeanThreads, 2) void gt_dense_fwd_lean_kernel(Csr 
         if (i < n) {
           float *lrow = pstage + rp[i];
           float *grow = attn_edge + (size_t)head * g.nnz + e0 + rp[i];
+          auto scatter = [&](float *row) {
 #pragma unroll
-          for (int jt = 0; jt < NT; ++jt) {
-            if (jt < ntile) {
-              const unsigned w = *reinterpret_cast<const unsigned *>(mrow + 16 * jt);
+            for (int jt = 0; jt < NT; ++jt) {
+              if (jt < ntile) {
+                const unsigned w = *reinterpret_cast<const unsigned *>(mrow + 16 * jt);
 #pragma unroll
-              for (int r = 0; r < 4; ++r) {
-                const unsigned slot = (w >> (8 * r)) & 0xFFu;
-                if (slot != 0xFFu) {
-                  if (stage_attn) lrow[slot] = S[s][jt][r] * inv[s];
-                  else grow[slot] = S[s][jt][r] * inv[s];
+                for (int r = 0; r < 4; ++r) {
+                  const unsigned slot = (w >> (8 * r)) & 0xFFu;
+                  if (slot != 0xFFu) row[slot] = S[s][jt][r] * inv[s];
                 }
               }
             }
-          }
+          };
+          if (stage_attn) scatter(lrow);
+          else scatter(grow);
         }
         if (stage_attn) {  // the strip streams its own contiguous slice of attn_edge out
           wave_sync();

@@ -66,10 +66,13 @@ struct DenseDrop {
 
 // FR: the real feature width.  Widths below the narrowest MFMA k-step (f = 16: the heads of multi-head GT configs) run
 // zero-padded on the 32-wide layout (F below); for FR >= 32 every padding guard folds away at compile time.
-template <int FR, bool WRITE_ATTN, int NS, int CR, int NCH, bool GAT = false>
+// MULTI: the workgroup loops over the heads of its range (GT, h > 1); false: one head, no loop (values that are live
+// around a loop -- the prefetch registers -- would be spilled in the single-head kernel too)
+template <int FR, bool WRITE_ATTN, int NS, int CR, int NCH, bool GAT = false, bool MULTI = false>
 __device__ __forceinline__ void dense_fwd_body(float *lds, int lds_bytes, const Csr &g, int n0, int n, int e0, int ne,
-                                               int head, const float *__restrict__ Q, const float *__restrict__ K,
-                                               const float *__restrict__ V, float *__restrict__ attn_edge,
+                                               int head, int nheads, const float *__restrict__ Q,
+                                               const float *__restrict__ K, const float *__restrict__ V,
+                                               float *__restrict__ attn_edge,
                                                float *__restrict__ out, float slope = 0.f,
                                                float *__restrict__ stat_max = nullptr,
                                                float *__restrict__ stat_sum = nullptr,
@@ -90,9 +93,16 @@ __device__ __forceinline__ void dense_fwd_body(float *lds, int lds_bytes, const 
   float *pstage = acl + (GAT ? npad : 0);                          // [ne] normalised attention values, if it fits
   const size_t fixed_bytes = (size_t)(reinterpret_cast<char *>(pstage) - reinterpret_cast<char *>(lds));
   const bool stage_attn = WRITE_ATTN && fixed_bytes + (size_t)ne * 4 <= (size_t)lds_bytes;
+  // GT: the workgroup takes the heads head .. head + nheads - 1 of its range one after the other -- the edge loads and
+  // the byte map are shared, the next head's K image and Q rows travel while the current head's P V product runs
+  // (GAT: nheads = 1; its attn_col staging and dropout map are per head)
   const size_t hf = (size_t)g.h * fr, hoff = (size_t)head * fr;
   const float *Qb = Q + (size_t)n0 * hf + hoff, *Kb = K + (size_t)n0 * hf + hoff, *Vb = V + (size_t)n0 * hf + hoff;
   float *Ob = out + (size_t)n0 * hf + hoff;
+  const int hend = MULTI ? head + nheads : head + 1;
+  // the next head's K image and Q rows are fetched under the current head's P V product for narrow heads only: wide ones
+  // have the registers for neither (they would spill around the loop) nor the need (a head is long)
+  constexpr bool kNextHeadPrefetch = MULTI && F <= 32;
   (void)Qb;
   (void)Kb;
 
@@ -126,21 +136,28 @@ __device__ __forceinline__ void dense_fwd_body(float *lds, int lds_bytes, const 
   dense_stage_load<F, CR>(st, GAT ? Vb : Kb, hf, 0, n, fr);  // the first image: K rows (GAT: X rows)
   float4 qa[NS][KT], qb[NS][KT];  // this lane's pieces of its strips' Q rows, raw: converted after the map is built
   float ar[NS];
+  auto q_fetch = [&](const float *Qhead) {  // (GT) the strips' Q rows of one head
 #pragma unroll
-  for (int s = 0; s < NS; ++s) {
-    const LaneIds L = lane_ids();
-    const int i = min((wave + 8 * s) * 16 + L.mi, n - 1);
-    if constexpr (GAT) {
-      ar[s] = Q[(size_t)(n0 + i) * g.h + head];
-    } else {
+    for (int s = 0; s < NS; ++s) {
+      const LaneIds L = lane_ids();
+      const int i = min((wave + 8 * s) * 16 + L.mi, n - 1);
       const unsigned off = (unsigned)i * (unsigned)hf;
 #pragma unroll
       for (int t = 0; t < KT; ++t) {
         const unsigned c = (FR == F || 32 * t + 8 * L.mq < fr) ? 32u * t + 8u * L.mq : 0u;  // (past fr: zeroed below)
-        qa[s][t] = ld32_f4(Qb, off + c);
-        qb[s][t] = ld32_f4(Qb, off + c + 4);
+        qa[s][t] = ld32_f4(Qhead, off + c);
+        qb[s][t] = ld32_f4(Qhead, off + c + 4);
       }
     }
+  };
+  if constexpr (GAT) {
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const LaneIds L = lane_ids();
+      ar[s] = Q[(size_t)(n0 + min((wave + 8 * s) * 16 + L.mi, n - 1)) * g.h + head];
+    }
+  } else {
+    q_fetch(Qb);
   }
   {
     const int tid = opaque_tid();
@@ -169,6 +186,7 @@ __device__ __forceinline__ void dense_fwd_body(float *lds, int lds_bytes, const 
       else map[i * MS + j] = (unsigned char)(e - rp[i]);
     }
   }
+  for (int hd = head;; ++hd) {  // ---- one head of the range per trip (MULTI) ----------------------------------------
   // The image's power-of-two scale needs the largest magnitude over the whole workgroup: one more barrier here (the
   // later images post theirs ahead of a barrier that is there anyway).
   wg_max_post(smax, dense_stage_absmax<F, CR>(st));
@@ -287,8 +305,8 @@ __device__ __forceinline__ void dense_fwd_body(float *lds, int lds_bytes, const 
       inv[s] = (sum != 0.f) ? 1.f / sum : 0.f;
       if constexpr (GAT) {  // training forward: the row statistics the backward recomputes P from
         if (stat_max && i < n && L.mq == 0) {
-          stat_max[(size_t)(n0 + i) * g.h + head] = (mx == -INFINITY) ? -1e38f : mx;
-          stat_sum[(size_t)(n0 + i) * g.h + head] = sum;
+          stat_max[(size_t)(n0 + i) * g.h + hd] = (mx == -INFINITY) ? -1e38f : mx;
+          stat_sum[(size_t)(n0 + i) * g.h + hd] = sum;
         }
         if (mask_h) {  // attention dropout after the softmax: the row sum counted every edge, the product skips
           inv[s] *= drop.scale;  // the dropped ones
@@ -306,26 +324,27 @@ __device__ __forceinline__ void dense_fwd_body(float *lds, int lds_bytes, const 
         // contiguous slice out), else straight from the registers (scattered 4-byte stores)
         if (i < n) {
           float *lrow = pstage + rp[i];
-          float *grow = attn_edge + (size_t)head * g.nnz + e0 + rp[i];
+          float *grow = attn_edge + (size_t)hd * g.nnz + e0 + rp[i];
+          auto scatter = [&](float *row) {  // (one copy per destination: the choice is not re-decided per pair)
 #pragma unroll
-          for (int jt = 0; jt < NT; ++jt) {
-            if (jt < ntile) {
-              const unsigned w = *reinterpret_cast<const unsigned *>(mrow + 16 * jt);
+            for (int jt = 0; jt < NT; ++jt) {
+              if (jt < ntile) {
+                const unsigned w = *reinterpret_cast<const unsigned *>(mrow + 16 * jt);
 #pragma unroll
-              for (int r = 0; r < 4; ++r) {
-                const unsigned slot = (w >> (8 * r)) & 0xFFu;
-                if (slot != 0xFFu) {
-                  if (stage_attn) lrow[slot] = S[s][jt][r] * inv[s];
-                  else grow[slot] = S[s][jt][r] * inv[s];
+                for (int r = 0; r < 4; ++r) {
+                  const unsigned slot = (w >> (8 * r)) & 0xFFu;
+                  if (slot != 0xFFu) row[slot] = S[s][jt][r] * inv[s];
                 }
               }
             }
-          }
+          };
+          if (stage_attn) scatter(lrow);
+          else scatter(grow);
         }
         if (stage_attn) {
           wave_sync();
           const int s0 = rp[strip * 16], s1 = rp[min(n, strip * 16 + 16)];
-          float *dst = attn_edge + (size_t)head * g.nnz + e0;
+          float *dst = attn_edge + (size_t)hd * g.nnz + e0;
           for (int e = s0 + (int)(threadIdx.x & (kWave - 1)); e < s1; e += kWave) dst[e] = pstage[e];
         }
       }
@@ -349,7 +368,12 @@ __device__ __forceinline__ void dense_fwd_body(float *lds, int lds_bytes, const 
       const float prev_inv = isc.inv;
       isc = pow2_scale(wg_max_read(smax));
       dense_stage_store<F, CR>(st, ihi, ilo, isc.s, fr);
-      if (c + 1 < NCH) dense_stage_load<F, CR>(st, Vb, hf, (c + 1) * CR, n, fr);
+      if (c + 1 < NCH) {
+        dense_stage_load<F, CR>(st, Vb, hf, (c + 1) * CR, n, fr);
+      } else if (kNextHeadPrefetch && hd + 1 < hend) {  // the next head's first image and Q rows
+        dense_stage_load<F, CR>(st, Kb + fr, hf, 0, n, fr);
+        q_fetch(Qb + fr);
+      }
       if (c > 0) {  // accumulated under the previous chunk's scale
         const float ratio = prev_inv * isc.s;
 #pragma unroll
@@ -385,6 +409,13 @@ __device__ __forceinline__ void dense_fwd_body(float *lds, int lds_bytes, const 
     }
   }
   DFGNN_DSTAMP(5)
+  if (!MULTI || hd + 1 >= hend) break;
+  Qb += fr; Kb += fr; Vb += fr; Ob += fr;
+  if constexpr (!kNextHeadPrefetch) {
+    dense_stage_load<F, CR>(st, Kb, hf, 0, n, fr);
+    q_fetch(Qb);
+  }
+  }  // (heads)
   DFGNN_DSTAMP(6)
 }
 
@@ -398,12 +429,21 @@ __global__ __launch_bounds__(kDenseThreads) void gt_dense_fwd_kernel(Csr g, cons
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int n0 = fit[2 * blockIdx.x], n1 = fit[2 * blockIdx.x + 1] & kPlanRangeMask;
   const int n = n1 - n0, e0 = g.row_ptr[n0], ne = g.row_ptr[n1] - e0;
-  if (n <= kDenseChunkRows)
-    dense_fwd_body<F, WRITE_ATTN, 1, kDenseChunkRows, 1>(lds, lds_bytes, g, n0, n, e0, ne, blockIdx.y, Q, K, V, attn_edge, out);
-  else if (n <= kDenseWideRows)
-    dense_fwd_body<F, WRITE_ATTN, 2, kDenseWideRows, 1>(lds, lds_bytes, g, n0, n, e0, ne, blockIdx.y, Q, K, V, attn_edge, out);
-  else
-    dense_fwd_body<F, WRITE_ATTN, 2, kDenseChunkRows, 2>(lds, lds_bytes, g, n0, n, e0, ne, blockIdx.y, Q, K, V, attn_edge, out);
+  if (g.h == 1) {
+    if (n <= kDenseChunkRows)
+      dense_fwd_body<F, WRITE_ATTN, 1, kDenseChunkRows, 1>(lds, lds_bytes, g, n0, n, e0, ne, 0, 1, Q, K, V, attn_edge, out);
+    else if (n <= kDenseWideRows)
+      dense_fwd_body<F, WRITE_ATTN, 2, kDenseWideRows, 1>(lds, lds_bytes, g, n0, n, e0, ne, 0, 1, Q, K, V, attn_edge, out);
+    else
+      dense_fwd_body<F, WRITE_ATTN, 2, kDenseChunkRows, 2>(lds, lds_bytes, g, n0, n, e0, ne, 0, 1, Q, K, V, attn_edge, out);
+  } else {  // every head of the range in this workgroup: edge loads and byte map once
+    if (n <= kDenseChunkRows)
+      dense_fwd_body<F, WRITE_ATTN, 1, kDenseChunkRows, 1, false, true>(lds, lds_bytes, g, n0, n, e0, ne, 0, g.h, Q, K, V, attn_edge, out);
+    else if (n <= kDenseWideRows)
+      dense_fwd_body<F, WRITE_ATTN, 2, kDenseWideRows, 1, false, true>(lds, lds_bytes, g, n0, n, e0, ne, 0, g.h, Q, K, V, attn_edge, out);
+    else
+      dense_fwd_body<F, WRITE_ATTN, 2, kDenseChunkRows, 2, false, true>(lds, lds_bytes, g, n0, n, e0, ne, 0, g.h, Q, K, V, attn_edge, out);
+  }
 #ifdef DFGNN_STAMPS
   if (threadIdx.x == 0 && dfgnn_dense_stamps)
     dfgnn_dense_stamps[((size_t)blockIdx.x * gridDim.y + blockIdx.y) * 16 + 15] = ((unsigned long long)n << 32) | (unsigned)ne;
@@ -424,13 +464,13 @@ __global__ __launch_bounds__(kDenseThreads) void gat_dense_fwd_kernel(Csr g, con
   const int n0 = fit[2 * blockIdx.x], n1 = fit[2 * blockIdx.x + 1] & kPlanRangeMask;
   const int n = n1 - n0, e0 = g.row_ptr[n0], ne = g.row_ptr[n1] - e0;
   if (n <= kDenseChunkRows)
-    dense_fwd_body<F, false, 1, kDenseChunkRows, 1, true>(lds, lds_bytes, g, n0, n, e0, ne, blockIdx.y, attn_row, attn_col, X,
+    dense_fwd_body<F, false, 1, kDenseChunkRows, 1, true>(lds, lds_bytes, g, n0, n, e0, ne, blockIdx.y, 1, attn_row, attn_col, X,
                                                           nullptr, out, slope, edge_max, edge_sum, drop);
   else if (n <= kDenseWideRows)
-    dense_fwd_body<F, false, 2, kDenseWideRows, 1, true>(lds, lds_bytes, g, n0, n, e0, ne, blockIdx.y, attn_row, attn_col, X,
+    dense_fwd_body<F, false, 2, kDenseWideRows, 1, true>(lds, lds_bytes, g, n0, n, e0, ne, blockIdx.y, 1, attn_row, attn_col, X,
                                                          nullptr, out, slope, edge_max, edge_sum, drop);
   else
-    dense_fwd_body<F, false, 2, kDenseChunkRows, 2, true>(lds, lds_bytes, g, n0, n, e0, ne, blockIdx.y, attn_row, attn_col, X,
+    dense_fwd_body<F, false, 2, kDenseChunkRows, 2, true>(lds, lds_bytes, g, n0, n, e0, ne, blockIdx.y, 1, attn_row, attn_col, X,
                                                           nullptr, out, slope, edge_max, edge_sum, drop);
 }
 
@@ -1027,7 +1067,7 @@ int launch_gt_dense_fwd(const Csr &g, const Plan &p, const float *Q, const float
   return dispatch_dense(g.f, [&](auto fc) {
     constexpr int F = decltype(fc)::value;
     if (nbig > 0) {
-      const dim3 grid(nbig, g.h);
+      const dim3 grid(nbig, 1);  // (a workgroup loops over the heads of its range)
       if (attn_edge) {
         if (int rc = set_max_lds(gt_dense_fwd_kernel<F, true>)) return rc;
         gt_dense_fwd_kernel<F, true><<<grid, kDenseThreads, kLdsBytes, s>>>(g, p.fit(), Q, K, V, attn_edge, out, kLdsBytes);
