@@ -306,6 +306,10 @@ def main():
         import fused_gatconv
         from _binding_util import build_plan
         from DFGNN.utils import GraphedStep
+        # (start the secondary figures from a clean allocator: with some step counts the cached blocks left by the timed loops
+        #  made every gat_forward output allocation miss the cache and doubled its time between events)
+        del out, attn, gedge, dQ, dK, dV
+        torch.cuda.empty_cache()
         with torch.no_grad():
             ar, ac, X = S.gat_features(m, h, f, seed=6, device=dev)
             go, emax, esum, mask = fused_gatconv.gat_forward(ar, ac, W.row_ptr, W.col_ind, 0.2, X, 0.0)

@@ -276,6 +276,34 @@ __device__ __forceinline__ void dense_kblock_mma(f32x4 (&acc)[F / 16], const h16
   }
 }
 
+// The same k-block for TWO operand fragments Y0, Y1 (two 16-column strips of the other matrix) and NFT feature tiles
+// starting at tile ft0: the X fragments are fetched once and used twice.  A wave that owns 2 strips x F/32 tiles instead of
+// 1 strip x F/16 tiles reads a third less from LDS per MFMA (operand fetches ~ perimeter of the register block), and
+// these products are bound by the LDS fragment traffic of the hi / lo images, not by the matrix pipe.
+template <int NFT>
+__device__ __forceinline__ void dense_kblock_mma2(f32x4 (&acc0)[NFT], f32x4 (&acc1)[NFT], const h16 *ihi, const h16 *ilo,
+                                                  int xoff, int second, const hx8 &yh0, const hx8 &yl0, const hx8 &yh1,
+                                                  const hx8 &yl1) {
+  hx8 xh[NFT], xl[NFT];
+#pragma unroll
+  for (int k = 0; k < NFT; ++k) {
+    xh[k] = dense_tr_pair(ihi + xoff + 16 * k, second);
+    xl[k] = dense_tr_pair(ilo + xoff + 16 * k, second);
+  }
+#pragma unroll
+  for (int k = 0; k < NFT; ++k) acc0[k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh[k], yh0, acc0[k], 0, 0, 0);
+#pragma unroll
+  for (int k = 0; k < NFT; ++k) acc1[k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh[k], yh1, acc1[k], 0, 0, 0);
+#pragma unroll
+  for (int k = 0; k < NFT; ++k) acc0[k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xl[k], yh0, acc0[k], 0, 0, 0);
+#pragma unroll
+  for (int k = 0; k < NFT; ++k) acc1[k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xl[k], yh1, acc1[k], 0, 0, 0);
+#pragma unroll
+  for (int k = 0; k < NFT; ++k) acc0[k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh[k], yl0, acc0[k], 0, 0, 0);
+#pragma unroll
+  for (int k = 0; k < NFT; ++k) acc1[k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh[k], yl1, acc1[k], 0, 0, 0);
+}
+
 // acc[ft] += Image^T (features 16 ft .., image rows 32 jb ..) . Y, Y given as the accumulator pair (y0, y1) of a
 // D^T strip (permuted k order, see the header): the "P V" product of the forward.  yscale: power-of-two scale of Y.
 template <int F, int GMAX = 4>

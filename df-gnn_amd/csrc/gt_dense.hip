@@ -92,7 +92,7 @@ __device__ __forceinline__ void dense_fwd_body(float *lds, int lds_bytes, const 
   float *acl = smax + kDenseWaves;                                 // [npad] attn_col of the range (GAT only)
   float *pstage = acl + (GAT ? npad : 0);                          // [ne] normalised attention values, if it fits
   const size_t fixed_bytes = (size_t)(reinterpret_cast<char *>(pstage) - reinterpret_cast<char *>(lds));
-  const bool stage_attn = WRITE_ATTN && fixed_bytes + (size_t)ne * 4 <= (size_t)lds_bytes;
+  const bool stage_attn = WRITE_ATTN && fixed_bytes + ((size_t)ne + kDenseThreads) * 4 <= (size_t)lds_bytes;  // (+ dump words)
   // GT: the workgroup takes the heads head .. head + nheads - 1 of its range one after the other -- the edge loads and
   // the byte map are shared, the next head's K image and Q rows travel while the current head's P V product runs
   // (GAT: nheads = 1; its attn_col staging and dropout map are per head)
@@ -325,7 +325,10 @@ __device__ __forceinline__ void dense_fwd_body(float *lds, int lds_bytes, const 
         if (i < n) {
           float *lrow = pstage + rp[i];
           float *grow = attn_edge + (size_t)hd * g.nnz + e0 + rp[i];
-          auto scatter = [&](float *row) {  // (one copy per destination: the choice is not re-decided per pair)
+          if (stage_attn) {
+            // LDS staging, branch-free: a pair that is no edge writes into this lane's own dump word instead of being
+            // masked out (an exec-mask round trip per pair costs more than the store)
+            float *dump = pstage + ne + (threadIdx.x & (kDenseThreads - 1));
 #pragma unroll
             for (int jt = 0; jt < NT; ++jt) {
               if (jt < ntile) {
@@ -333,13 +336,24 @@ __device__ __forceinline__ void dense_fwd_body(float *lds, int lds_bytes, const 
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                   const unsigned slot = (w >> (8 * r)) & 0xFFu;
-                  if (slot != 0xFFu) row[slot] = S[s][jt][r] * inv[s];
+                  float *dst = (slot != 0xFFu) ? lrow + slot : dump;
+                  *dst = S[s][jt][r] * inv[s];
                 }
               }
             }
-          };
-          if (stage_attn) scatter(lrow);
-          else scatter(grow);
+          } else {
+#pragma unroll
+            for (int jt = 0; jt < NT; ++jt) {
+              if (jt < ntile) {
+                const unsigned w = *reinterpret_cast<const unsigned *>(mrow + 16 * jt);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                  const unsigned slot = (w >> (8 * r)) & 0xFFu;
+                  if (slot != 0xFFu) grow[slot] = S[s][jt][r] * inv[s];
+                }
+              }
+            }
+          }
         }
         if (stage_attn) {
           wave_sync();
@@ -713,8 +727,35 @@ __device__ __forceinline__ void dense_bwd_body(float *lds, const Csr &g, int n0,
     if (j < n)
       dense_store_acc<1, (FR < F)>(acc, oscale, outb, (unsigned)j * (unsigned)hf + 16u * ft + 4u * L.mq, accumulate, 16 * ft + 4 * L.mq, fr);
   };
+  // the same product for a single tile of <= 128 x 128: wave w takes the column strips 2 (w / 2), 2 (w / 2) + 1 and the
+  // feature tiles of half w % 2 (dense_kblock_mma2: the image fragments are shared by the two strips)
+  constexpr bool kBlocked = NBLK == 1 && U == kDenseWaves && FR == F && FT >= 4;
+  auto column_block = [&](float *outb, int ni, float oscale) {
+    constexpr int NFT = kBlocked ? FT / 2 : 2;  // (compiled for every instance, used by the blocked ones)
+    const LaneIds L = lane_ids();
+    const int cs0 = 2 * (wave >> 1), ft0 = NFT * (wave & 1);
+    f32x4 acc0[NFT], acc1[NFT];
+#pragma unroll
+    for (int k = 0; k < NFT; ++k) acc0[k] = acc1[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ib = 0; ib < RBP / 32; ++ib) {
+      if (32 * ib < ni) {
+        const int yoff = (32 * ib + 4 * L.mq + L.tq) * TB + 16 * cs0 + 4 * L.tp;
+        const hx8 yh0 = dense_tr_pair(Tb + yoff, 16 * TB), yl0 = dense_tr_pair(Tb + yoff + TS, 16 * TB);
+        const hx8 yh1 = dense_tr_pair(Tb + yoff + 16, 16 * TB), yl1 = dense_tr_pair(Tb + yoff + 16 + TS, 16 * TB);
+        dense_kblock_mma2<NFT>(acc0, acc1, ihi, ilo, (32 * ib + 4 * L.mq + L.tq) * RS + 4 * L.tp + 16 * ft0, 16 * RS, yh0,
+                               yl0, yh1, yl1);
+      }
+    }
+    dense_store_rows<NFT>(acc0, oscale, outb + 16 * ft0, (unsigned)hf, cs0 * 16 + L.mi, n, L);
+    dense_store_rows<NFT>(acc1, oscale, outb + 16 * ft0, (unsigned)hf, cs0 * 16 + 16 + L.mi, n, L);
+  };
   auto column_phase = [&](float *outb, int j0, int ni, bool accumulate, float oscale) {
     const int nstrips = min(U, (n - j0 + 15) >> 4);
+    if constexpr (kBlocked) {  // (one tile: j0 = 0, nothing to accumulate onto)
+      if (2 * (wave >> 1) < nstrips) column_block(outb, ni, oscale);
+      return;
+    }
     if (wave < nstrips) column_strip(outb, j0, wave, ni, accumulate, oscale);
     if (U > kDenseWaves)
       for (int unit = wave; unit < (nstrips - kDenseWaves) * FT; unit += kDenseWaves)
@@ -933,7 +974,31 @@ __device__ __forceinline__ void dense_bwd_body(float *lds, const Csr &g, int n0,
       image_prefetch(Qb, i0, i0 + ni);      // next image: Q rows of this row block
       lds_barrier();
       DFGNN_DSTAMP(5)
-      if (row_wave) {
+      if constexpr (kBlocked) {
+        // wave w: the dS rows of strips 2 (w / 2), 2 (w / 2) + 1 (from the tile: every strip put its own there before
+        // the barrier) against the feature tiles of half w % 2 of K
+        constexpr int NFT = FT / 2;
+        const int cs0 = 2 * (wave >> 1), ft0 = NFT * (wave & 1);
+        if (cs0 * 16 < ni) {
+          const LaneIds L = lane_ids();
+          f32x4 q0[NFT], q1[NFT];
+#pragma unroll
+          for (int k = 0; k < NFT; ++k) q0[k] = q1[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+          const h16 *srow = Tb + (cs0 * 16 + L.mi) * TB + 8 * L.mq;
+#pragma unroll
+          for (int jb = 0; jb < CW / 32; ++jb) {
+            if (32 * jb < nj) {
+              const hx8 sh0 = *reinterpret_cast<const hx8 *>(srow + 32 * jb), sl0 = *reinterpret_cast<const hx8 *>(srow + TS + 32 * jb);
+              const hx8 sh1 = *reinterpret_cast<const hx8 *>(srow + 16 * TB + 32 * jb),
+                        sl1 = *reinterpret_cast<const hx8 *>(srow + 16 * TB + TS + 32 * jb);
+              dense_kblock_mma2<NFT>(q0, q1, ihi, ilo, (32 * jb + 8 * L.mq + L.tq) * RS + 4 * L.tp + 16 * ft0, 4 * RS, sh0, sl0,
+                                     sh1, sl1);
+            }
+          }
+          dense_store_rows<NFT>(q0, kinv * ts.inv, dQb + 16 * ft0, (unsigned)hf, i0 + cs0 * 16 + L.mi, i0 + ni, L);
+          dense_store_rows<NFT>(q1, kinv * ts.inv, dQb + 16 * ft0, (unsigned)hf, i0 + cs0 * 16 + 16 + L.mi, i0 + ni, L);
+        }
+      } else if (row_wave) {
         const LaneIds L = lane_ids();
         const h16 *srow = Tb + (wave * 16 + L.mi) * TB + 8 * L.mq;
 #pragma unroll

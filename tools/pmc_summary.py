@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Summarise rocprofv3 --pmc passes (one directory per pass) into per-kernel means per launch.
 usage: pmc_summary.py <workload string> <dir> [<dir> ...]   -> JSON on stdout
+A workload string of the form "... m=<m> nnz=<nnz> h=<h> f=<f> build=<id>" also fills the m / nnz / h / f / build_id keys
+bench.py matches against before it quotes `roofline.traffic` from the file.
 HBM traffic = FETCH_SIZE x 2 (gfx950 counts 128-byte fetches as 64, MI355X_MICROARCH.md) + WRITE_SIZE, both in KB."""
 import csv, glob, json, sys
 from collections import defaultdict
@@ -15,7 +17,10 @@ for d in dirs:
             per[(r["Dispatch_Id"], name, r["Counter_Name"])] += float(r["Counter_Value"])
         for (disp, name, ctr), v in per.items():
             acc[name][ctr].append(v)
-out = {"workload": work, "note": "rocprofv3 --pmc, one pass per counter group, means per launch (first launch of each "
+import re
+tags = {k: re.search(rf"\b{k}=(\w+)", work) for k in ("m", "nnz", "h", "f", "build")}
+out = {"workload": work, **{k: int(v.group(1)) for k, v in tags.items() if v and k != "build"},
+       "build_id": tags["build"].group(1) if tags["build"] else None, "note": "rocprofv3 --pmc, one pass per counter group, means per launch (first launch of each "
        "kernel dropped as warm-up); FETCH_SIZE / WRITE_SIZE in KB, FETCH_SIZE doubled for gfx950",
        "traffic": {}, "counters_mean_per_launch": {}}
 for name, ctrs in acc.items():

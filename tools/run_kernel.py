@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Profiling helper: run one hot-path entry point a few times on the C3 workload (for rocprofv3).
-usage: python3 tools/run_kernel.py [fwd|bwd|fwd_infer|gat|gat_train|gat_train_drop] [iters] [batch_size]"""
+usage: python3 tools/run_kernel.py [fwd|bwd|fwd_infer|gat|gat_train|gat_train_drop|c4] [iters] [batch_size]"""
 import os
 import sys
 
@@ -20,6 +20,17 @@ what = sys.argv[1] if len(sys.argv) > 1 else "fwd"
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 bs = int(sys.argv[3]) if len(sys.argv) > 3 else 1024
 dev = "cuda:0"
+if what == "c4":  # BASELINE.json configs[3]: GAT 'tiling' on the reddit-like graph
+    from DFGNN.layers.util import preprocess_CSR
+    from DFGNN.operators import fused_gatconv as gatops
+    g = S.reddit_like().to(dev)
+    row_ptr, col_ind, val, _ = preprocess_CSR(g)
+    ar, ac, X = S.gat_features(g.num_nodes(), 1, 128, seed=4, device=dev)
+    for _ in range(iters):
+        gatops.GATConvFuse_inference_tiling(ar, ac, row_ptr, col_ind, 0.2, X)
+    torch.cuda.synchronize()
+    print("done c4", iters, g.num_nodes(), g.num_edges())
+    sys.exit(0)
 g = S.pattern_like(batch_size=bs, seed=1).to(dev)
 A, rows, row_ptr, col_ind, val, col_ptr, row_ind, val_idx, smem = preprocess_Hyper_fw_bw(g)
 m = g.num_nodes()
