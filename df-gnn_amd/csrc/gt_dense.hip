@@ -1120,39 +1120,42 @@ static bool lean_enabled() {
   return on;
 }
 
+static int launch_gt_dense_fwd_single(const Csr &g, const Plan &p, const float *Q, const float *K, const float *V,
+                                      float *attn_edge, float *out, hipStream_t s) {
+  const dim3 grid(p.num_dense, 1);
+  return dispatch_dense(g.f, [&](auto fc) {
+    constexpr int F = decltype(fc)::value;
+    if (attn_edge) {
+      if (int rc = set_max_lds(gt_dense_fwd_kernel<F, true>)) return rc;
+      gt_dense_fwd_kernel<F, true><<<grid, kDenseThreads, kLdsBytes, s>>>(g, p.fit(), Q, K, V, attn_edge, out, kLdsBytes);
+    } else {
+      if (int rc = set_max_lds(gt_dense_fwd_kernel<F, false>)) return rc;
+      gt_dense_fwd_kernel<F, false><<<grid, kDenseThreads, kLdsBytes, s>>>(g, p.fit(), Q, K, V, nullptr, out, kLdsBytes);
+    }
+    return launch_status();
+  });
+}
+
+// The ranges of more than 128 nodes need the 512-thread kernel (one workgroup per CU); a batch without any takes the
+// 256-thread kernel, two workgroups per CU (dfgnn_dense_lean.hpp: ~12 % faster on such batches).  A MIXED batch stays on the
+// 512-thread kernel as a whole: run as two kernels the classes serialise -- one after the other on the caller's stream the
+// second waits for the first one's tail (forward 108 -> 130 us on the headline batch), and forked onto a side stream of the
+// library's own (fork / join events) the two grids still ran back to back on this runtime (127 us).
 int launch_gt_dense_fwd(const Csr &g, const Plan &p, const float *Q, const float *K, const float *V,
                         float *attn_edge, float *out, hipStream_t s) {
   if (p.num_dense == 0) return 0;
-  // the ranges of more than 128 nodes come first in the list and take the 512-thread kernel (one workgroup per CU);
-  // the others -- for the widths it is built for -- the 256-thread kernel, two workgroups per CU (dfgnn_dense_lean.hpp)
-  // -- when there are none of the former: two launches would serialise (the second waits for the first one's tail), which
-  // costs a mixed batch more than the second kernel gains
-  const int nlean = ((g.f == 64 || g.f == 128) && lean_enabled() && p.num_dense_wide == 0) ? p.num_dense : 0;
-  const int nbig = p.num_dense - nlean;
+  const bool lean = (g.f == 64 || g.f == 128) && g.h == 1 && p.num_dense_wide == 0 && lean_enabled();
+  if (!lean) return launch_gt_dense_fwd_single(g, p, Q, K, V, attn_edge, out, s);
+  const dim3 grid(p.num_dense, 1);
   return dispatch_dense(g.f, [&](auto fc) {
     constexpr int F = decltype(fc)::value;
-    if (nbig > 0) {
-      const dim3 grid(nbig, 1);  // (a workgroup loops over the heads of its range)
-      if (attn_edge) {
-        if (int rc = set_max_lds(gt_dense_fwd_kernel<F, true>)) return rc;
-        gt_dense_fwd_kernel<F, true><<<grid, kDenseThreads, kLdsBytes, s>>>(g, p.fit(), Q, K, V, attn_edge, out, kLdsBytes);
-      } else {
-        if (int rc = set_max_lds(gt_dense_fwd_kernel<F, false>)) return rc;
-        gt_dense_fwd_kernel<F, false><<<grid, kDenseThreads, kLdsBytes, s>>>(g, p.fit(), Q, K, V, nullptr, out, kLdsBytes);
-      }
-      if (int rc = launch_status()) return rc;
-    }
     if constexpr (F == 64 || F == 128) {
-      if (nlean > 0) {
-        const dim3 grid(nlean, g.h);
-        const int *fit = p.fit() + 2 * (size_t)nbig;
-        if (attn_edge) {
-          if (int rc = set_max_lds(gt_dense_fwd_lean_kernel<F, true>)) return rc;
-          gt_dense_fwd_lean_kernel<F, true><<<grid, kLeanThreads, kLeanLdsBytes, s>>>(g, fit, Q, K, V, attn_edge, out);
-        } else {
-          if (int rc = set_max_lds(gt_dense_fwd_lean_kernel<F, false>)) return rc;
-          gt_dense_fwd_lean_kernel<F, false><<<grid, kLeanThreads, kLeanLdsBytes, s>>>(g, fit, Q, K, V, nullptr, out);
-        }
+      if (attn_edge) {
+        if (int rc = set_max_lds(gt_dense_fwd_lean_kernel<F, true>)) return rc;
+        gt_dense_fwd_lean_kernel<F, true><<<grid, kLeanThreads, kLeanLdsBytes, s>>>(g, p.fit(), Q, K, V, attn_edge, out);
+      } else {
+        if (int rc = set_max_lds(gt_dense_fwd_lean_kernel<F, false>)) return rc;
+        gt_dense_fwd_lean_kernel<F, false><<<grid, kLeanThreads, kLeanLdsBytes, s>>>(g, p.fit(), Q, K, V, nullptr, out);
       }
     }
     return launch_status();
