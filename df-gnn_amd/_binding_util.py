@@ -111,7 +111,7 @@ def build_plan(indptr, indices, f):
     m, nnz = indptr.size(0) - 1, indices.size(0)
     L = _n.lib()
     with torch.cuda.device(indptr.device):
-        buf = torch.empty(int(L.dfgnn_plan_ints(m)), dtype=torch.int32, device=indptr.device)
+        buf = torch.empty(int(L.dfgnn_plan_ints(m, nnz)), dtype=torch.int32, device=indptr.device)
         meta = (ctypes.c_int * 12)()
         _n.check(L.dfgnn_plan_build(m, nnz, f, indptr.data_ptr(), indices.data_ptr(), buf.data_ptr(),
                                     ctypes.addressof(meta), stream_ptr(indptr.device)), "dfgnn_plan_build")

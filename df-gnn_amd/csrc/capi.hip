@@ -19,7 +19,8 @@ inline bool make_plan(Plan &p, const int *plan_dev, const int *meta, int m, int 
   // by the per-edge gathers: a 1024-thread workgroup per range only adds fixed cost there (measured on the
   // Peptides-like config: 279 us resident vs 180 us general for fwd+bwd), so such graphs keep the general kernels.
   if ((long)nnz < (long)kBlockMinAvgDegree * m) return false;
-  p = Plan{plan_dev, meta[0], meta[1], meta[2], meta[3], m, nnz, f, meta[8], meta[9], meta[10]};
+  p = Plan{plan_dev, meta[0], meta[1], meta[2], meta[3], m, nnz, f, meta[8], meta[9], meta[10], meta[11]};
+  if (p.num_dense > 0 && p.coords_off <= 0) return false;  // (a plan of an older layout)
   return true;
 }
 

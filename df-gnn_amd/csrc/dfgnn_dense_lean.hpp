@@ -125,14 +125,13 @@ __global__ __launch_bounds__(kLeanThreads, 2) void gt_dense_fwd_lean_kernel(Csr 
     const int tid = opaque_tid();
     if (tid <= n) rp_mine = g.row_ptr[n0 + tid];
   }
-  int pre_i[PRE], pre_j[PRE];
+  unsigned pre_c[PRE];  // packed (row, column) within the range (plan.hip: coords)
   {
     const int tid = opaque_tid();
 #pragma unroll
     for (int k = 0; k < PRE; ++k) {
       const unsigned e = (unsigned)min(tid + k * kLeanThreads, ne - 1);
-      pre_i[k] = ld32(g.rows + e0, e);
-      pre_j[k] = ld32(g.col_ind + e0, e);
+      pre_c[k] = ld32(g.coords + e0, e);
     }
   }
   image_fetch(Kb);
@@ -149,23 +148,22 @@ __global__ __launch_bounds__(kLeanThreads, 2) void gt_dense_fwd_lean_kernel(Csr 
     for (int k = 0; k < PRE; ++k) {
       const int e = tid + k * kLeanThreads;
       if (e < ne) {
-        const int i = pre_i[k] - n0, j = pre_j[k] - n0;
+        const int i = pre_c[k] >> 8, j = pre_c[k] & 0xFF;
         map[i * MS + j] = (unsigned char)(e - rp[i]);
       }
     }
     constexpr int B = 8;
     for (int base = PRE * kLeanThreads; base < ne; base += B * kLeanThreads) {
-      int bi[B], bj[B];
+      unsigned bc[B];
 #pragma unroll
       for (int k = 0; k < B; ++k) {
         const unsigned e = (unsigned)min(base + tid + k * kLeanThreads, ne - 1);
-        bi[k] = ld32(g.rows + e0, e);
-        bj[k] = ld32(g.col_ind + e0, e);
+        bc[k] = ld32(g.coords + e0, e);
       }
 #pragma unroll
       for (int k = 0; k < B; ++k) {
         const int e = base + tid + k * kLeanThreads;
-        if (e < ne) map[(bi[k] - n0) * MS + (bj[k] - n0)] = (unsigned char)(e - rp[bi[k] - n0]);
+        if (e < ne) map[(bc[k] >> 8) * MS + (bc[k] & 0xFF)] = (unsigned char)(e - rp[bc[k] >> 8]);
       }
     }
   }

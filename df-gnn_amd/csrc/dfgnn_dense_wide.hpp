@@ -59,15 +59,14 @@ __device__ __forceinline__ void dense_bwd_wide_body(float *lds, const Csr &g, in
 
   DFGNN_WSTAMP(0)
   // ---- prologue: edges and the first image are requested before anything else ------------------------------------
-  int pi[PRE], pj[PRE];
+  unsigned pc[PRE];  // packed (row, column) within the range (plan.hip: coords)
   float pa[PRE];
   {
     const int tid = opaque_tid();
 #pragma unroll
     for (int k = 0; k < PRE; ++k) {
       const unsigned e = (unsigned)min(tid + k * kDenseThreads, max(ne, 1) - 1);
-      pi[k] = ld32(g.rows + e0, e);
-      pj[k] = ld32(g.col_ind + e0, e);
+      pc[k] = ld32(g.coords + e0, e);
       pa[k] = ld32(attn_h, e);
     }
   }
@@ -94,28 +93,28 @@ __device__ __forceinline__ void dense_bwd_wide_body(float *lds, const Csr &g, in
     const int tid = opaque_tid();
     for (int k = tid; k < NP * TS / 4; k += kDenseThreads) reinterpret_cast<float4 *>(T)[k] = make_float4(0.f, 0.f, 0.f, 0.f);
     lds_barrier();
-    auto put = [&](int i, int j, float p) {
+    auto put = [&](unsigned c, float p) {
+      const int at = (int)(c >> 8) * TB + (int)(c & 0xFF);
       const h16 hh = (h16)(p * kUnitScale);
-      Tb[(i - n0) * TB + (j - n0)] = hh;
-      Tb[(i - n0) * TB + TS + (j - n0)] = (h16)fmaf(p, kUnitScale, -(float)hh);
+      Tb[at] = hh;
+      Tb[at + TS] = (h16)fmaf(p, kUnitScale, -(float)hh);
     };
 #pragma unroll
     for (int k = 0; k < PRE; ++k)
-      if (tid + k * kDenseThreads < ne) put(pi[k], pj[k], pa[k]);
+      if (tid + k * kDenseThreads < ne) put(pc[k], pa[k]);
     constexpr int B = 8;
     for (int base = PRE * kDenseThreads; base < ne; base += B * kDenseThreads) {
-      int bi[B], bj[B];
+      unsigned bc[B];
       float ba[B];
 #pragma unroll
       for (int k = 0; k < B; ++k) {
         const unsigned e = (unsigned)min(base + tid + k * kDenseThreads, ne - 1);
-        bi[k] = ld32(g.rows + e0, e);
-        bj[k] = ld32(g.col_ind + e0, e);
+        bc[k] = ld32(g.coords + e0, e);
         ba[k] = ld32(attn_h, e);
       }
 #pragma unroll
       for (int k = 0; k < B; ++k)
-        if (base + tid + k * kDenseThreads < ne) put(bi[k], bj[k], ba[k]);
+        if (base + tid + k * kDenseThreads < ne) put(bc[k], ba[k]);
     }
   }
   image_post(0);

@@ -12,6 +12,9 @@ struct Csr {
   const int *col_ind;
   const int *rows;   // sorted COO row ids (hyper / softmax formats), may be null for CSR-only ops
   const float *val;  // may be null (all ones)
+  // matrix-core kernels only (set by their launchers from the plan): uint16 per edge, (row << 8 | column) within the
+  // edge's dense range -- read instead of rows / col_ind
+  const unsigned short *coords = nullptr;
 };
 
 constexpr int kErrBadArg = -1;
@@ -46,6 +49,8 @@ struct Plan {              // host view of a built plan (see plan.hip for the de
   int num_fit, num_spill, max_fit_nodes, max_fit_edges, m, nnz, f, num_edge_global;
   int num_dense;           // the first num_dense fit ranges carry kPlanDense (gt_dense.hip)
   int num_dense_wide = 0;  // ... and the first num_dense_wide of those have more than 128 nodes
+  int coords_off = 0;      // int32 offset of the packed edge coordinates of the dense ranges (plan.hip)
+  const unsigned short *coords() const { return reinterpret_cast<const unsigned short *>(dev + coords_off); }
   const int *fit() const { return dev + kPlanHeader; }
   const int *spill() const { return dev + kPlanHeader + 2 * (size_t)m; }
 };

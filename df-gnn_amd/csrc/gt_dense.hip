@@ -117,7 +117,7 @@ __device__ __forceinline__ void dense_fwd_body(float *lds, int lds_bytes, const 
     if constexpr (GAT)
       if (tid < n) ac_mine = K[(size_t)(n0 + tid) * g.h + head];
   }
-  int pre_i[kDensePre], pre_j[kDensePre];
+  unsigned pre_c[kDensePre];         // packed (row, column) of the edges within the range (plan.hip: coords)
   float pre_m[GAT ? kDensePre : 1];  // GAT with dropout: the edges' uniform randoms
   const float *mask_h = nullptr;     // ... of this head, edge e at mask_h[(e0 + e) * h]
   if constexpr (GAT)
@@ -127,8 +127,7 @@ __device__ __forceinline__ void dense_fwd_body(float *lds, int lds_bytes, const 
 #pragma unroll
     for (int k = 0; k < kDensePre; ++k) {
       const unsigned e = (unsigned)min(tid + k * kDenseThreads, ne - 1);  // clamped: plain loads
-      pre_i[k] = ld32(g.rows + e0, e);
-      pre_j[k] = ld32(g.col_ind + e0, e);
+      pre_c[k] = ld32(g.coords + e0, e);
       if constexpr (GAT) pre_m[k] = mask_h ? mask_h[(size_t)e * g.h] : 1.f;
     }
   }
@@ -175,13 +174,14 @@ __device__ __forceinline__ void dense_fwd_body(float *lds, int lds_bytes, const 
     for (int k = 0; k < kDensePre; ++k) {
       const int e = tid + k * kDenseThreads;
       if (e < ne) {
-        const int i = pre_i[k] - n0, j = pre_j[k] - n0;
+        const int i = pre_c[k] >> 8, j = pre_c[k] & 0xFF;
         if (GAT && mask_h) map[i * MS + j] = (pre_m[GAT ? k : 0] > drop.drop) ? 0 : 1;
         else map[i * MS + j] = (unsigned char)(e - rp[i]);
       }
     }
     for (int e = tid + kDensePre * kDenseThreads; e < ne; e += kDenseThreads) {
-      const int i = g.rows[e0 + e] - n0, j = g.col_ind[e0 + e] - n0;
+      const unsigned c = g.coords[e0 + e];
+      const int i = c >> 8, j = c & 0xFF;
       if (GAT && mask_h) map[i * MS + j] = (mask_h[(size_t)e * g.h] > drop.drop) ? 0 : 1;
       else map[i * MS + j] = (unsigned char)(e - rp[i]);
     }
@@ -588,7 +588,7 @@ __device__ __forceinline__ void dense_bwd_body(float *lds, const Csr &g, int n0,
   // Edges of a row block (CSR order, contiguous) are fetched several per thread at a time -- loads first, then the
   // scatter into the fp32 tile -- so that a batch costs one memory round trip; the first batch of a range is
   // fetched ahead of everything else.
-  int pi[PRE], pj[PRE];
+  unsigned pc[PRE];  // packed (row, column) within the range (plan.hip: coords)
   float pa[PRE];
   auto edges_prefetch = [&](int ea, int eb) {  // first PRE edges per thread of the row block [ea, eb)
     const int tid = opaque_tid();
@@ -597,8 +597,7 @@ __device__ __forceinline__ void dense_bwd_body(float *lds, const Csr &g, int n0,
       // clamped: plain loads (a row block without edges -- rows with in-edges only -- reads the last edge, unused)
       const unsigned e = (unsigned)min(tid + k * kDenseThreads, max(eb - ea, 1) - 1);
       const int ea0 = min(ea, g.nnz - 1);
-      pi[k] = ld32(g.rows + ea0, e);
-      pj[k] = ld32(g.col_ind + ea0, e);
+      pc[k] = ld32(g.coords + ea0, e);
       if constexpr (!GAT) pa[k] = ld32(attn_h + ea0, e);
       else pa[k] = ga.drop.mask ? ga.drop.mask[((size_t)ea0 + e) * g.h + head] : 1.f;
     }
@@ -623,10 +622,10 @@ __device__ __forceinline__ void dense_bwd_body(float *lds, const Csr &g, int n0,
     const int tid = opaque_tid();
 #pragma unroll
     for (int k = 0; k < PRE; ++k) {
-      const int j = pj[k] - n0;
+      const int i = pc[k] >> 8, j = pc[k] & 0xFF;
       if (tid + k * kDenseThreads < eb - ea && j < CW) {
-        if constexpr (GAT) T[(pi[k] - n0) * TS + j] = gat_p(pi[k] - n0, pj[k] - n0, pa[k]);
-        else T[(pi[k] - n0) * TS + j] = pa[k];
+        if constexpr (GAT) T[i * TS + j] = gat_p(i, j, pa[k]);
+        else T[i * TS + j] = pa[k];
       }
     }
   };
@@ -635,22 +634,21 @@ __device__ __forceinline__ void dense_bwd_body(float *lds, const Csr &g, int n0,
     if (!opened) tile_clear();
     constexpr int B = 8;
     for (int base = opened ? PRE * kDenseThreads : 0; base < eb - ea; base += B * kDenseThreads) {
-      int bi[B], bj[B];
+      unsigned bc[B];
       float ba[B];
 #pragma unroll
       for (int k = 0; k < B; ++k) {
         const unsigned e = (unsigned)min(base + tid + k * kDenseThreads, eb - ea - 1);  // (eb > ea inside this loop)
-        bi[k] = ld32(g.rows + ea, e);
-        bj[k] = ld32(g.col_ind + ea, e);
+        bc[k] = ld32(g.coords + ea, e);
         if constexpr (!GAT) ba[k] = ld32(attn_h + ea, e);
         else ba[k] = ga.drop.mask ? ga.drop.mask[((size_t)ea + e) * g.h + head] : 1.f;
       }
 #pragma unroll
       for (int k = 0; k < B; ++k) {
-        const int j = bj[k] - n0 - j0;
+        const int i = bc[k] >> 8, jj = bc[k] & 0xFF, j = jj - j0;
         if (base + tid + k * kDenseThreads < eb - ea && j >= 0 && j < CW) {
-          if constexpr (GAT) T[(bi[k] - n0 - i0) * TS + j] = gat_p(bi[k] - n0, bj[k] - n0, ba[k]);
-          else T[(bi[k] - n0 - i0) * TS + j] = ba[k];
+          if constexpr (GAT) T[(i - i0) * TS + j] = gat_p(i, jj, ba[k]);
+          else T[(i - i0) * TS + j] = ba[k];
         }
       }
     }
@@ -1120,8 +1118,10 @@ static bool lean_enabled() {
   return on;
 }
 
-static int launch_gt_dense_fwd_single(const Csr &g, const Plan &p, const float *Q, const float *K, const float *V,
+static int launch_gt_dense_fwd_single(const Csr &g_in, const Plan &p, const float *Q, const float *K, const float *V,
                                       float *attn_edge, float *out, hipStream_t s) {
+  Csr g = g_in;
+  g.coords = p.coords();
   const dim3 grid(p.num_dense, 1);
   return dispatch_dense(g.f, [&](auto fc) {
     constexpr int F = decltype(fc)::value;
@@ -1141,11 +1141,13 @@ static int launch_gt_dense_fwd_single(const Csr &g, const Plan &p, const float *
 // 512-thread kernel as a whole: run as two kernels the classes serialise -- one after the other on the caller's stream the
 // second waits for the first one's tail (forward 108 -> 130 us on the headline batch), and forked onto a side stream of the
 // library's own (fork / join events) the two grids still ran back to back on this runtime (127 us).
-int launch_gt_dense_fwd(const Csr &g, const Plan &p, const float *Q, const float *K, const float *V,
+int launch_gt_dense_fwd(const Csr &g_in, const Plan &p, const float *Q, const float *K, const float *V,
                         float *attn_edge, float *out, hipStream_t s) {
   if (p.num_dense == 0) return 0;
-  const bool lean = (g.f == 64 || g.f == 128) && g.h == 1 && p.num_dense_wide == 0 && lean_enabled();
-  if (!lean) return launch_gt_dense_fwd_single(g, p, Q, K, V, attn_edge, out, s);
+  const bool lean = (g_in.f == 64 || g_in.f == 128) && g_in.h == 1 && p.num_dense_wide == 0 && lean_enabled();
+  if (!lean) return launch_gt_dense_fwd_single(g_in, p, Q, K, V, attn_edge, out, s);
+  Csr g = g_in;
+  g.coords = p.coords();
   const dim3 grid(p.num_dense, 1);
   return dispatch_dense(g.f, [&](auto fc) {
     constexpr int F = decltype(fc)::value;
@@ -1162,9 +1164,11 @@ int launch_gt_dense_fwd(const Csr &g, const Plan &p, const float *Q, const float
   });
 }
 
-int launch_gat_dense_fwd(const Csr &g, const Plan &p, const float *attn_row, const float *attn_col, float slope,
+int launch_gat_dense_fwd(const Csr &g_in, const Plan &p, const float *attn_row, const float *attn_col, float slope,
                          const float *X, float *out, hipStream_t s, float *edge_max, float *edge_sum,
                          const float *edge_mask, float attn_drop) {
+  Csr g = g_in;
+  g.coords = p.coords();
   if (p.num_dense == 0) return 0;
   const dim3 grid(p.num_dense, g.h);
   DenseDrop drop;
@@ -1178,10 +1182,12 @@ int launch_gat_dense_fwd(const Csr &g, const Plan &p, const float *attn_row, con
   });
 }
 
-int launch_gat_dense_bwd(const Csr &g, const Plan &p, const float *attn_row, const float *attn_col, float slope,
+int launch_gat_dense_bwd(const Csr &g_in, const Plan &p, const float *attn_row, const float *attn_col, float slope,
                          const float *X, const float *edge_max, const float *edge_sum, const float *grad_out,
                          float *grad_feat, float *grad_row, float *grad_col, hipStream_t s, const float *edge_mask,
                          float attn_drop) {
+  Csr g = g_in;
+  g.coords = p.coords();
   if (p.num_dense == 0) return 0;
   const dim3 grid(p.num_dense, g.h);
   GatBwdArgs ga{edge_max, edge_sum, slope, grad_row, grad_col, DenseDrop{}};
@@ -1194,9 +1200,11 @@ int launch_gat_dense_bwd(const Csr &g, const Plan &p, const float *attn_row, con
   });
 }
 
-int launch_gt_dense_bwd(const Csr &g, const Plan &p, const float *Q, const float *K, const float *V,
+int launch_gt_dense_bwd(const Csr &g_in, const Plan &p, const float *Q, const float *K, const float *V,
                         const float *attn_edge, const float *grad_out, float *dQ, float *dK, float *dV,
                         hipStream_t s) {
+  Csr g = g_in;
+  g.coords = p.coords();
   if (p.num_dense == 0) return 0;
   const dim3 grid(p.num_dense, g.h);
   return dispatch_dense(g.f, [&](auto fc) {

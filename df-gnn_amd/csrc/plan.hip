@@ -18,6 +18,10 @@
 //                                    largest first
 //   [12+2m .. 12+4m)    spill chunks (r0, r1) pairs, r1 - r0 <= kHyperRows
 //   [12+4m .. )         scratch: pairs[m] (cover, bad) as int2, bounds[m+1], count, rocPRIM temporary storage
+//   [hdr[11] .. )       coords: uint16[nnz], for every edge e of a dense range (i - n0) << 8 | (j - n0) -- its row and
+//                       column within the range (both < 256).  The matrix-core kernels read these 2 bytes per edge
+//                       instead of rows[e] and col_ind[e] (8 bytes): the sparse structure of a dense range costs a
+//                       quarter of the bytes, and the prologue that waits for it a quarter of the transfer.
 //
 // Build (all on the GPU, four steps, no host round trip before the final header copy):
 //   1. plan_row_extent_kernel  a 16-lane group per row: column extent [lo, hi] of the row, duplicate-edge check;
@@ -28,6 +32,7 @@
 //   3. rocprim::select         the open cuts (cover == 0) = ends of the natural closed ranges, in order
 //   4. plan_cut_kernel         one workgroup: greedy merge of the natural ranges (a serial walk over LDS copies),
 //                              classification, largest-first sort
+//   5. plan_coords_kernel      a workgroup per dense range (grid-stride), 16 lanes per row: the packed coordinates
 //
 // "Dense" (gt_dense.hip, dfgnn_dense.hpp): at most 255 nodes, at least one edge per 32 node pairs, f in {32, 64, 128}
 // and no duplicate edge in any row of the range -- the one thing a dense mask cannot represent.
@@ -134,7 +139,7 @@ __global__ __launch_bounds__(kPlanThreads) void plan_cut_kernel(int m, int nnz, 
                                                                 int merge_nodes,
                                                                 const int *__restrict__ row_ptr, int *plan,
                                                                 const PlanPair *pairs, const int *bounds,
-                                                                const int *count) {
+                                                                const int *count, int coords_off) {
   extern __shared__ __attribute__((aligned(16))) int plan_lds[];
   int *s_end = plan_lds;                    // [kPlanCache + 1] prefix form: range k = [s_end[k], s_end[k + 1])
   int *s_rp = s_end + kPlanCache + 1;       // [kPlanCache + 1] row_ptr at those nodes
@@ -251,7 +256,7 @@ __global__ __launch_bounds__(kPlanThreads) void plan_cut_kernel(int m, int nnz, 
       hdr[8] = s_stat[2];
       hdr[9] = s_stat[3];
       hdr[10] = s_stat[4];  // dense ranges of more than 128 nodes: they come first in the sorted list
-      hdr[11] = 0;
+      hdr[11] = coords_off;
       s_nfit = nfit;
     }
   } else if (t == 0) {
@@ -320,7 +325,7 @@ __global__ __launch_bounds__(kPlanThreads) void plan_cut_kernel(int m, int nnz, 
     hdr[8] = nglobal;
     hdr[9] = (nfit <= kPlanCache) ? ndense : 0;  // the dense ranges are only usable once sorted to the front (below)
     hdr[10] = (nfit <= kPlanCache) ? nwide : 0;
-    hdr[11] = 0;
+    hdr[11] = coords_off;
     s_nfit = nfit;
   }
   __syncthreads();
@@ -372,6 +377,24 @@ __global__ __launch_bounds__(kPlanThreads) void plan_cut_kernel(int m, int nnz, 
   }
 }
 
+// coords[e] of every edge of the dense ranges (the first hdr[9] fit ranges).  Runs after plan_cut_kernel on the same
+// stream; the range count is read on the device, so no host round trip.
+__global__ __launch_bounds__(256) void plan_coords_kernel(const int *__restrict__ row_ptr,
+                                                          const int *__restrict__ col_ind, const int *plan,
+                                                          unsigned short *__restrict__ coords) {
+  const int ndense = plan[9];
+  const int *fit = plan + kPlanHeader;
+  const int grp = threadIdx.x / kExtentLanes, gl = threadIdx.x % kExtentLanes;
+  for (int k = blockIdx.x; k < ndense; k += gridDim.x) {
+    const int n0 = fit[2 * k], n1 = fit[2 * k + 1] & kPlanRangeMask;
+    for (int i = n0 + grp; i < n1; i += 256 / kExtentLanes) {
+      const int ea = row_ptr[i], eb = row_ptr[i + 1];
+      for (int e = ea + gl; e < eb; e += kExtentLanes)
+        coords[e] = (unsigned short)(((i - n0) << 8) | ((col_ind[e] - n0) & 0xFF));
+    }
+  }
+}
+
 }  // namespace dfgnn
 
 using namespace dfgnn;
@@ -389,10 +412,14 @@ static size_t plan_temp_bytes(int m) {
   return ((a > b ? a : b) + 255) & ~(size_t)255;
 }
 
-// scratch after the fit / spill lists: pairs (2m ints), bounds (m + 1), count (1 + 2 pad), temp (aligned to 256 B)
-size_t dfgnn_plan_ints(int m) {
-  if (m < 0) return 0;
-  return kPlanHeader + 7 * (size_t)m + 4 + (plan_temp_bytes(m) + 256) / sizeof(int);
+// scratch after the fit / spill lists: pairs (2m ints), bounds (m + 1), count (1 + 2 pad), temp (aligned to 256 B);
+// then the packed edge coordinates (uint16[nnz], 16-byte aligned)
+static size_t plan_coords_off(int m) {
+  return (kPlanHeader + 7 * (size_t)m + 4 + (plan_temp_bytes(m) + 256) / sizeof(int) + 3) & ~(size_t)3;
+}
+size_t dfgnn_plan_ints(int m, int nnz) {
+  if (m < 0 || nnz < 0) return 0;
+  return plan_coords_off(m) + ((size_t)nnz + 1) / 2 + 4;
 }
 
 int dfgnn_plan_build(int m, int nnz, int f, const int *row_ptr, const int *col_ind, int *plan, int *meta_host,
@@ -426,9 +453,16 @@ int dfgnn_plan_build(int m, int nnz, int f, const int *row_ptr, const int *col_i
   if (hipError_t rc = hipFuncSetAttribute(reinterpret_cast<const void *>(plan_cut_kernel),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)kCutLds))
     return (int)rc;
+  const size_t coords_off = plan_coords_off(m);
+  if (coords_off > 0x7fffffffu) return kErrUnsupported;
   plan_cut_kernel<<<1, kPlanThreads, kCutLds, s>>>(m, nnz, f, kBlockLdsBudget, merge_nodes, row_ptr, plan, pairs, bounds,
-                                                   count);
+                                                   count, (int)coords_off);
   if (int rc = launch_status()) return rc;
+  if (nnz > 0) {
+    plan_coords_kernel<<<(unsigned)min(m, 2048), 256, 0, s>>>(row_ptr, col_ind, plan,
+                                                             reinterpret_cast<unsigned short *>(plan + coords_off));
+    if (int rc = launch_status()) return rc;
+  }
   if (hipError_t rc = hipMemcpyAsync(meta_host, plan, kPlanHeader * sizeof(int), hipMemcpyDeviceToHost, s)) return (int)rc;
   return (int)hipStreamSynchronize(s);
 }

@@ -98,7 +98,7 @@ def lib():
         L.dfgnn_error_string.restype = ctypes.c_char_p
         L.dfgnn_abi_version.restype = ctypes.c_int
         L.dfgnn_build_id.restype = ctypes.c_char_p
-        L.dfgnn_plan_ints.argtypes = [ctypes.c_int]
+        L.dfgnn_plan_ints.argtypes = [ctypes.c_int, ctypes.c_int]
         L.dfgnn_plan_ints.restype = ctypes.c_size_t
         L.dfgnn_preprocess_ws_bytes.argtypes = [ctypes.c_int, ctypes.c_int]
         L.dfgnn_preprocess_ws_bytes.restype = ctypes.c_size_t

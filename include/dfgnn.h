@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define DFGNN_ABI_VERSION 7
+#define DFGNN_ABI_VERSION 8
 
 #define DFGNN_E_BADARG (-1)      /* negative size / NULL required pointer                      */
 #define DFGNN_E_UNSUPPORTED (-2) /* feature width outside the compiled range (f > 1024, or     */
@@ -60,12 +60,14 @@ const char *dfgnn_build_id(void);
  * forward / backward use for them when val == NULL (unit edge values): masked dense attention on MFMA with
  * fp32-equivalent arithmetic (operands as fp16 hi + lo halves under power-of-two scales, fp32 accumulation:
  * ~3 x 2^-24 relative error per product, that of an fp32 FMA chain).
- *   plan       device buffer of dfgnn_plan_ints(m) int32
+ *   plan       device buffer of dfgnn_plan_ints(m, nnz) int32 (lists of ranges, build scratch and, for the
+ *              matrix-core kernels, 2 bytes per edge: its row and column within its dense range)
  *   meta_host  host buffer of 12 int32 filled on return: num_fit, num_spill, max_fit_nodes,
- *              max_fit_edges, m, nnz, f, lds_budget, num_edge_global, num_dense, 0, 0
+ *              max_fit_edges, m, nnz, f, lds_budget, num_edge_global, num_dense, num_dense_wide (dense ranges of
+ *              more than 128 nodes), coords_offset (int32 offset of the per-edge coordinates in `plan`)
  * dfgnn_plan_build synchronises `stream` (it copies the 12 header words back); nothing else in this
  * library does. */
-size_t dfgnn_plan_ints(int m);
+size_t dfgnn_plan_ints(int m, int nnz);
 int dfgnn_plan_build(int m, int nnz, int f, const int *row_ptr, const int *col_ind, int *plan,
                      int *meta_host, dfgnn_stream_t stream);
 
