@@ -1,0 +1,331 @@
+// dfgnn_dense_heads.hpp -- matrix-core GT forward for MULTI-HEAD configurations (h > 1, head width 16 / 32 / 64): one
+// workgroup per dense range takes every head of the range.
+//
+// The per-(range, head) form (dense_fwd_body with MULTI) stages a K image and a V image per head -- for a 16-wide head
+// that is a 128 x 16 slice zero-padded onto the 32-wide layout, 64-byte row segments from memory, five workgroup
+// barriers and two scale reductions per head -- although everything after the logits (the masked softmax, the attention
+// output, the P V product) is per-wave work that needs no barrier at all.  Here the heads are taken in GROUPS of 64
+// feature columns (4 / 2 / 1 heads):
+//   * the group's K columns and V columns are BOTH resident (two 64-wide fp16 hi / lo images, 256-byte row segments from
+//     memory, the next group's travelling in registers): two barriers per group, none per head;
+//   * a head's logits use the k-step of the K image that holds its columns (16-wide heads: the other head's half of the
+//     k-step is zeroed in the Q operand); its P V product touches only its own 16-feature tiles of the V image;
+//   * the byte map of the range lives in registers for all heads; the attention values of a strip are staged in a
+//     per-wave LDS area and streamed out as whole lines; the group's 64 output columns of a row are stored together.
+// Same numerics and operand layouts as dfgnn_dense.hpp.  Replaces, for such ranges, the same reference kernel as
+// gt_dense.hip's forward (fused_gtconv_hyper.cu:228-560, one launch covers all heads there too: blockIdx.y).
+#pragma once
+#include "dfgnn_dense.hpp"
+
+namespace dfgnn {
+
+constexpr int kHeadsGroupWidth = 64;
+
+// head widths / head counts this body takes (the others stay on dense_fwd_body)
+__host__ __device__ constexpr bool dense_heads_ok(int fr, int h) {
+  return h > 1 && (fr == 16 || fr == 32 || fr == 64) && (h * fr) % kHeadsGroupWidth == 0;
+}
+
+// NFT feature tiles starting at element offset xoff of a 32-deep k-block: acc[k] += X^T Y (see dense_kblock_mma); a single
+// tile keeps the three partial products in separate accumulators so that its MFMAs do not wait for each other
+template <int NFT>
+__device__ __forceinline__ void dense_kblock_mma_n(f32x4 (&acc)[NFT], f32x4 (&aux)[2], const h16 *ihi, const h16 *ilo,
+                                                   int xoff, int second, const hx8 &yh, const hx8 &yl) {
+  hx8 xh[NFT], xl[NFT];
+#pragma unroll
+  for (int k = 0; k < NFT; ++k) {
+    xh[k] = dense_tr_pair(ihi + xoff + 16 * k, second);
+    xl[k] = dense_tr_pair(ilo + xoff + 16 * k, second);
+  }
+  if constexpr (NFT == 1) {
+    acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh[0], yh, acc[0], 0, 0, 0);
+    aux[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xl[0], yh, aux[0], 0, 0, 0);
+    aux[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh[0], yl, aux[1], 0, 0, 0);
+  } else {
+#pragma unroll
+    for (int k = 0; k < NFT; ++k) acc[k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh[k], yh, acc[k], 0, 0, 0);
+#pragma unroll
+    for (int k = 0; k < NFT; ++k) acc[k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xl[k], yh, acc[k], 0, 0, 0);
+#pragma unroll
+    for (int k = 0; k < NFT; ++k) acc[k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh[k], yl, acc[k], 0, 0, 0);
+  }
+}
+
+// FR: head width; NS strips per wave, NP padded rows (128 / 160); n <= NP, n > 8 * 16 * (NS - 1)
+template <int FR, bool WRITE_ATTN, int NS, int NP>
+__device__ __forceinline__ void dense_fwd_heads_body(float *lds, int lds_bytes, const Csr &g, int n0, int n, int e0, int ne,
+                                                     const float *__restrict__ Q, const float *__restrict__ K,
+                                                     const float *__restrict__ V, float *__restrict__ attn_edge,
+                                                     float *__restrict__ out) {
+  constexpr int FW = kHeadsGroupWidth, G = FW / FR, NT = NP / 16, KTH = FR == 64 ? 2 : 1, FTH = FR / 16;
+  using D = DenseCfg<FW>;
+  constexpr int RS = D::RS, KT = D::KT, FT = D::FT;
+  // the next group's images travel in registers while the current group is computed -- when the registers allow it
+  // (one strip per wave); with two strips they are fetched at the group boundary
+  constexpr bool kPrefetch = NS == 1;
+  const int ngroups = g.h * FR / FW;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+  const int npad = (n + 31) & ~31, ntile = npad >> 4, nstrip = (n + 15) >> 4;
+  const int MS = npad + 4;
+  h16 *khi = reinterpret_cast<h16 *>(lds), *klo = khi + (size_t)NP * RS, *vhi = klo + (size_t)NP * RS, *vlo = vhi + (size_t)NP * RS;
+  unsigned char *map = reinterpret_cast<unsigned char *>(vlo + (size_t)NP * RS);
+  const int map_bytes = nstrip * 16 * MS;
+  int *rp = reinterpret_cast<int *>(map + ((map_bytes + 15) & ~15));
+  float *smax = reinterpret_cast<float *>(rp + ((n + 4) & ~3));  // [8] per-wave maxima of the K image, [8] of the V image
+  float *stage0 = smax + 2 * kDenseWaves;
+  // per-wave staging area of the attention values of one strip: cap floats + one dump word per lane
+  const int fixed_bytes = (int)(reinterpret_cast<char *>(stage0) - reinterpret_cast<char *>(lds));
+  const int cap = (((lds_bytes - fixed_bytes) / kDenseWaves) / 4 - kWave) & ~3;
+  float *wstage = stage0 + wave * (max(cap, 0) + kWave);
+  const size_t hf = (size_t)g.h * FR;
+  const float *Qb = Q + (size_t)n0 * hf, *Kb = K + (size_t)n0 * hf, *Vb = V + (size_t)n0 * hf;
+  float *Ob = out + (size_t)n0 * hf;
+
+  // ---- prologue: every long-latency load goes out before the first barrier, the small ones first -----------------------
+  int rp_mine = 0;
+  {
+    const int tid = opaque_tid();
+    if (tid <= n) rp_mine = g.row_ptr[n0 + tid];
+  }
+  unsigned pre_c[kDensePre];
+  {
+    const int tid = opaque_tid();
+#pragma unroll
+    for (int k = 0; k < kDensePre; ++k) {
+      const unsigned e = (unsigned)min(tid + k * kDenseThreads, ne - 1);
+      pre_c[k] = ld32(g.coords + e0, e);
+    }
+  }
+  DenseStageRegs<FW, NP> stK, stV;
+  dense_stage_load<FW, NP>(stK, Kb, hf, 0, n);
+  dense_stage_load<FW, NP>(stV, Vb, hf, 0, n);
+  float4 qa[NS][KT], qb[NS][KT];  // this lane's pieces of its strips' Q rows, the 64 columns of one group, raw
+  auto q_fetch = [&](const float *Qgroup) {
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const LaneIds L = lane_ids();
+      const unsigned off = (unsigned)min((wave + 8 * s) * 16 + L.mi, n - 1) * (unsigned)hf + 8u * L.mq;
+#pragma unroll
+      for (int t = 0; t < KT; ++t) {
+        qa[s][t] = ld32_f4(Qgroup, off + 32 * t);
+        qb[s][t] = ld32_f4(Qgroup, off + 32 * t + 4);
+      }
+    }
+  };
+  q_fetch(Qb);
+  {
+    const int tid = opaque_tid();
+    for (int k = tid; k < (map_bytes >> 2); k += kDenseThreads) reinterpret_cast<unsigned *>(map)[k] = 0xFFFFFFFFu;
+    if (tid <= n) rp[tid] = rp_mine - e0;
+  }
+  lds_barrier();
+  {  // byte map: position of every edge within its row (the plan guarantees distinct columns and rows < 255 long)
+    const int tid = opaque_tid();
+#pragma unroll
+    for (int k = 0; k < kDensePre; ++k) {
+      const int e = tid + k * kDenseThreads;
+      if (e < ne) {
+        const int i = pre_c[k] >> 8, j = pre_c[k] & 0xFF;
+        map[i * MS + j] = (unsigned char)(e - rp[i]);
+      }
+    }
+    for (int e = tid + kDensePre * kDenseThreads; e < ne; e += kDenseThreads) {
+      const unsigned c = g.coords[e0 + e];
+      const int i = c >> 8, j = c & 0xFF;
+      map[i * MS + j] = (unsigned char)(e - rp[i]);
+    }
+  }
+  Pow2Scale ksc{1.f, 1.f}, vsc{1.f, 1.f};
+  // group images: registers -> LDS around a barrier pair; the next group's are requested in between
+  auto images_commit = [&](int next_group) {
+    wg_max_post(smax, dense_stage_absmax<FW, NP>(stK));
+    wg_max_post(smax + kDenseWaves, dense_stage_absmax<FW, NP>(stV));
+    lds_barrier();  // (every strip is done with the previous group's images; the map is complete)
+    ksc = pow2_scale(wg_max_read(smax));
+    vsc = pow2_scale(wg_max_read(smax + kDenseWaves));
+    dense_stage_store<FW, NP>(stK, khi, klo, ksc.s);
+    dense_stage_store<FW, NP>(stV, vhi, vlo, vsc.s);
+    if (kPrefetch && next_group < ngroups) {
+      dense_stage_load<FW, NP>(stK, Kb + next_group * FW, hf, 0, n);
+      dense_stage_load<FW, NP>(stV, Vb + next_group * FW, hf, 0, n);
+    }
+    lds_barrier();
+  };
+  images_commit(1);
+  // the strips' rows of the byte map, for every head
+  unsigned mw[NS][NT];
+  int row_e0[NS], strip_e0[NS], strip_e1[NS];  // rp of this lane's row; edge range of the strip
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    const LaneIds L = lane_ids();
+    const int strip = wave + 8 * s, i = strip * 16 + L.mi;
+    const unsigned char *mrow = map + min(i, nstrip * 16 - 1) * MS + 4 * L.mq;
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt)
+      mw[s][jt] = (strip < nstrip && jt < ntile) ? *reinterpret_cast<const unsigned *>(mrow + 16 * jt) : 0xFFFFFFFFu;
+    row_e0[s] = rp[min(i, n)];
+    strip_e0[s] = rp[min(n, strip * 16)];
+    strip_e1[s] = rp[min(n, strip * 16 + 16)];
+  }
+
+  for (int gq = 0;; ++gq) {  // ---- one group of 64 feature columns (G heads) per trip --------------------------------
+    f32x4 o[NS][FT];
+#pragma unroll
+    for (int q = 0; q < G; ++q) {
+      const int head = gq * G + q;
+      constexpr int kStepsPerHead = KTH;
+      const int t0 = (q * FR) / 32;  // first k-step of the head's columns in the group's images
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        const int strip = wave + 8 * s;
+        const LaneIds L = lane_ids();
+        // ---- this head's Q operand of the strip: fp16 halves under the strip's own power-of-two scale (done for a
+        //      strip past the range as well: nothing here may sit under a branch, the loads below least of all) -------
+        hx8 qh[kStepsPerHead], ql[kStepsPerHead];
+        float qinv;
+        {
+          const bool valid = strip * 16 + L.mi < n && (FR >= 32 || (L.mq >> 1) == (q & 1));
+          float4 xa[kStepsPerHead], xb[kStepsPerHead];
+          float qm = 0.f;
+#pragma unroll
+          for (int t = 0; t < kStepsPerHead; ++t) {
+            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+            xa[t] = valid ? qa[s][t0 + t] : z;
+            xb[t] = valid ? qb[s][t0 + t] : z;
+            qm = fmaxf(qm, absmax8(xa[t], xb[t]));
+          }
+          const Pow2Scale qs = pow2_scale(wave_max(qm));
+          qinv = qs.inv;
+#pragma unroll
+          for (int t = 0; t < kStepsPerHead; ++t) split_hx8(xa[t], xb[t], qs.s, qh[t], ql[t]);
+        }
+        // the last head of the group has converted its Q: the raw rows of the next group can be requested
+        if (q == G - 1 && s == NS - 1 && gq + 1 < ngroups) q_fetch(Qb + (gq + 1) * FW);
+        if (strip < nstrip) {
+          // One strip per wave: the compiler takes everything that depends only on the map words -- edge predicates, slots,
+          // staging addresses -- out of the head loop (they are the same for every head), a welcome saving.  With two strips
+          // per wave that is 80 more live registers and spills: there the words are re-read behind an optimisation barrier.
+          unsigned mwh[NT];
+#pragma unroll
+          for (int jt = 0; jt < NT; ++jt) {
+            mwh[jt] = mw[s][jt];
+            if constexpr (NS > 1) asm volatile("" : "+v"(mwh[jt]));
+          }
+          // ---- S^T tiles of the strip ------------------------------------------------------------------------------
+          f32x4 S[NT];
+#pragma unroll
+          for (int u = 0; u < NT; ++u) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            if (u < ntile) {
+#pragma unroll
+              for (int t = 0; t < kStepsPerHead; ++t) {
+                const int off = (16 * u + L.mi) * RS + 8 * L.mq + 32 * (t0 + t);
+                const hx8 ah = *reinterpret_cast<const hx8 *>(khi + off), al = *reinterpret_cast<const hx8 *>(klo + off);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, qh[t], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, ql[t], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, qh[t], acc, 0, 0, 0);
+              }
+            }
+            S[u] = acc;
+          }
+          // ---- masked row softmax in registers: the logits are S x c (c a power of two), the exponent is taken base 2 -
+          const float c2 = (ksc.inv * qinv) * 1.4426950408889634f;
+          float mx = -INFINITY;
+#pragma unroll
+          for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const bool edge = ((mwh[jt] >> (8 * r)) & 0xFFu) != 0xFFu;
+              const float x = edge ? S[jt][r] : -INFINITY;
+              S[jt][r] = x;
+              mx = fmaxf(mx, x);
+            }
+          mx = xor16_32_max(mx);
+          const float base = (mx == -INFINITY) ? 0.f : mx * c2;
+          float sum = 0.f;
+#pragma unroll
+          for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float p = __builtin_amdgcn_exp2f(fmaf(S[jt][r], c2, -base));  // 2^-inf = 0 for the masked pairs
+              S[jt][r] = p;
+              sum += p;
+            }
+          sum = xor16_32_sum(sum);
+          const float inv = (sum != 0.f) ? 1.f / sum : 0.f;
+          if constexpr (WRITE_ATTN) {
+            float *dst = attn_edge + (size_t)head * g.nnz + e0;
+            const int s0 = strip_e0[s], s1 = strip_e1[s];
+            if (s1 - s0 <= cap) {  // (wave-uniform) through this wave's staging area, then out as whole lines
+              float *lrow = wstage + (row_e0[s] - s0);
+              float *dump = wstage + cap + (threadIdx.x & (kWave - 1));
+#pragma unroll
+              for (int jt = 0; jt < NT; ++jt) {
+                if (jt < ntile) {
+#pragma unroll
+                  for (int r = 0; r < 4; ++r) {
+                    const unsigned slot = (mwh[jt] >> (8 * r)) & 0xFFu;
+                    float *d = (slot != 0xFFu) ? lrow + slot : dump;
+                    *d = S[jt][r] * inv;
+                  }
+                }
+              }
+              wave_sync();
+              for (int e = s0 + (int)(threadIdx.x & (kWave - 1)); e < s1; e += kWave) dst[e] = wstage[e - s0];
+              wave_sync();  // (the area is reused by the wave's next strip / head)
+            } else {  // a strip with more edges than the area holds: straight from the registers
+              float *grow = dst + row_e0[s];
+#pragma unroll
+              for (int jt = 0; jt < NT; ++jt) {
+                if (jt < ntile) {
+#pragma unroll
+                  for (int r = 0; r < 4; ++r) {
+                    const unsigned slot = (mwh[jt] >> (8 * r)) & 0xFFu;
+                    if (slot != 0xFFu) grow[slot] = S[jt][r] * inv;
+                  }
+                }
+              }
+            }
+          }
+          // ---- O^T tiles of this head = V^T P^T: its FTH feature tiles of the group's V image ------------------------
+          f32x4 acc[FTH], aux[2];
+#pragma unroll
+          for (int k = 0; k < FTH; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+          aux[0] = aux[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int jb = 0; jb < NP / 32; ++jb) {
+            if (2 * jb < ntile) {
+              hx8 yh, yl;
+              dense_split8(S[2 * jb], S[2 * jb + 1], kUnitScale, yh, yl);
+              dense_kblock_mma_n<FTH>(acc, aux, vhi, vlo, (32 * jb + 4 * L.mq + L.tq) * RS + 4 * L.tp + 16 * (q * FTH), 16 * RS, yh, yl);
+            }
+          }
+          const float oscale = inv * (vsc.inv * kUnitScaleInv);
+#pragma unroll
+          for (int k = 0; k < FTH; ++k) {
+            if constexpr (FTH == 1) acc[k] += aux[0] + aux[1];
+            o[s][q * FTH + k] = acc[k] * oscale;
+          }
+        } else {
+#pragma unroll
+          for (int k = 0; k < FTH; ++k) o[s][q * FTH + k] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+      }
+    }
+    // the group's 64 output columns of every row, as whole lines
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const LaneIds L = lane_ids();
+      if ((wave + 8 * s) * 16 < n)
+        dense_store_rows<FT>(o[s], 1.f, Ob + gq * FW, (unsigned)hf, (wave + 8 * s) * 16 + L.mi, n, L);
+    }
+    if (gq + 1 >= ngroups) break;
+    if constexpr (!kPrefetch) {
+      dense_stage_load<FW, NP>(stK, Kb + (gq + 1) * FW, hf, 0, n);
+      dense_stage_load<FW, NP>(stV, Vb + (gq + 1) * FW, hf, 0, n);
+    }
+    images_commit(gq + 2);
+  }
+}
+
+}  // namespace dfgnn

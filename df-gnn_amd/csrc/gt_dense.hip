@@ -35,8 +35,26 @@ __device__ unsigned long long *dfgnn_dense_stamps = nullptr;  // [wg][16] phase 
 #define DFGNN_DSTAMP(k)                                                                             \
   if (threadIdx.x == 0 && dfgnn_dense_stamps)                                                       \
     dfgnn_dense_stamps[((size_t)blockIdx.x * gridDim.y + blockIdx.y) * 16 + (k)] = __builtin_amdgcn_s_memtime();
+// per-workgroup trace (same diagnostic build): [wg][8] = entry time, exit time (s_memtime), hardware id
+// (XCC_ID << 32 | HW_ID: which CU ran it), entry and exit time on the constant 100 MHz clock
+__device__ unsigned long long *dfgnn_wg_trace = nullptr;
+#define DFGNN_TRACE_IN                                                                              \
+  if (threadIdx.x == 0 && dfgnn_wg_trace) {                                                         \
+    unsigned long long *t_ = dfgnn_wg_trace + ((size_t)blockIdx.x * gridDim.y + blockIdx.y) * 8;   \
+    t_[0] = __builtin_amdgcn_s_memtime();                                                           \
+    t_[3] = __builtin_amdgcn_s_memrealtime();                                                       \
+    t_[2] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | __builtin_amdgcn_s_getreg((31 << 11) | 4); \
+  }
+#define DFGNN_TRACE_OUT                                                                             \
+  if (threadIdx.x == 0 && dfgnn_wg_trace) {                                                         \
+    unsigned long long *t_ = dfgnn_wg_trace + ((size_t)blockIdx.x * gridDim.y + blockIdx.y) * 8;   \
+    t_[1] = __builtin_amdgcn_s_memtime();                                                           \
+    t_[4] = __builtin_amdgcn_s_memrealtime();                                                       \
+  }
 #else
 #define DFGNN_DSTAMP(k)
+#define DFGNN_TRACE_IN
+#define DFGNN_TRACE_OUT
 #endif
 
 }  // namespace dfgnn
@@ -48,6 +66,7 @@ __device__ unsigned long long *dfgnn_dense_stamps = nullptr;  // [wg][16] phase 
 #endif
 #include "dfgnn_dense_wide.hpp"
 #include "dfgnn_dense_lean.hpp"
+#include "dfgnn_dense_heads.hpp"
 namespace dfgnn {
 
 // =====================================================================================================================
@@ -441,6 +460,7 @@ __global__ __launch_bounds__(kDenseThreads) void gt_dense_fwd_kernel(Csr g, cons
                                                                      float *__restrict__ attn_edge,
                                                                      float *__restrict__ out, int lds_bytes) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  DFGNN_TRACE_IN
   const int n0 = fit[2 * blockIdx.x], n1 = fit[2 * blockIdx.x + 1] & kPlanRangeMask;
   const int n = n1 - n0, e0 = g.row_ptr[n0], ne = g.row_ptr[n1] - e0;
   if (g.h == 1) {
@@ -451,6 +471,21 @@ __global__ __launch_bounds__(kDenseThreads) void gt_dense_fwd_kernel(Csr g, cons
     else
       dense_fwd_body<F, WRITE_ATTN, 2, kDenseChunkRows, 2>(lds, lds_bytes, g, n0, n, e0, ne, 0, 1, Q, K, V, attn_edge, out);
   } else {  // every head of the range in this workgroup: edge loads and byte map once
+    if constexpr (F == 16 || F == 32 || F == 64) {
+      if (dense_heads_ok(F, g.h) && n <= kDenseWideRows) {  // heads in groups of 64 columns (dfgnn_dense_heads.hpp)
+#ifdef DFGNN_HEADS_VARIANT  // diagnostic builds: one geometry only (register use of a single body)
+        constexpr int hv = DFGNN_HEADS_VARIANT;
+#else
+        constexpr int hv = -1;
+#endif
+        if ((hv < 0 && n <= kDenseChunkRows) || hv == 0)
+          dense_fwd_heads_body<F, WRITE_ATTN, 1, kDenseChunkRows>(lds, lds_bytes, g, n0, n, e0, ne, Q, K, V, attn_edge, out);
+        else if (hv != 0)
+          dense_fwd_heads_body<F, WRITE_ATTN, 2, kDenseWideRows>(lds, lds_bytes, g, n0, n, e0, ne, Q, K, V, attn_edge, out);
+        DFGNN_TRACE_OUT
+        return;
+      }
+    }
     if (n <= kDenseChunkRows)
       dense_fwd_body<F, WRITE_ATTN, 1, kDenseChunkRows, 1, false, true>(lds, lds_bytes, g, n0, n, e0, ne, 0, g.h, Q, K, V, attn_edge, out);
     else if (n <= kDenseWideRows)
@@ -458,6 +493,7 @@ __global__ __launch_bounds__(kDenseThreads) void gt_dense_fwd_kernel(Csr g, cons
     else
       dense_fwd_body<F, WRITE_ATTN, 2, kDenseChunkRows, 2, false, true>(lds, lds_bytes, g, n0, n, e0, ne, 0, g.h, Q, K, V, attn_edge, out);
   }
+  DFGNN_TRACE_OUT
 #ifdef DFGNN_STAMPS
   if (threadIdx.x == 0 && dfgnn_dense_stamps)
     dfgnn_dense_stamps[((size_t)blockIdx.x * gridDim.y + blockIdx.y) * 16 + 15] = ((unsigned long long)n << 32) | (unsigned)ne;
@@ -1067,6 +1103,7 @@ __global__ __launch_bounds__(kDenseThreads) void gt_dense_bwd_kernel(
     const float *__restrict__ V, const float *__restrict__ attn_edge, const float *__restrict__ dO,
     float *__restrict__ dQ, float *__restrict__ dK, float *__restrict__ dV) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  DFGNN_TRACE_IN
   const int n0 = fit[2 * blockIdx.x], n1 = fit[2 * blockIdx.x + 1] & kPlanRangeMask;
   const int n = n1 - n0, e0 = g.row_ptr[n0], ne = g.row_ptr[n1] - e0;
 #ifdef DFGNN_BWD_VARIANT  // diagnostic builds: one geometry only (register use / ISA of a single body)
@@ -1088,6 +1125,7 @@ __global__ __launch_bounds__(kDenseThreads) void gt_dense_bwd_kernel(
 #endif
   else
     dense_bwd_body<F, kDenseChunkRows, 2>(lds, g, n0, n, e0, ne, blockIdx.y, Q, K, V, attn_edge, dO, dQ, dK, dV);
+  DFGNN_TRACE_OUT
 #ifdef DFGNN_STAMPS
   if (threadIdx.x == 0 && dfgnn_dense_stamps)
     dfgnn_dense_stamps[((size_t)blockIdx.x * gridDim.y + blockIdx.y) * 16 + 15] = ((unsigned long long)n << 32) | (unsigned)ne;
@@ -1220,5 +1258,8 @@ int launch_gt_dense_bwd(const Csr &g_in, const Plan &p, const float *Q, const fl
 #ifdef DFGNN_STAMPS
 extern "C" int dfgnn_debug_set_dense_stamps(void *p) {
   return (int)hipMemcpyToSymbol(HIP_SYMBOL(dfgnn::dfgnn_dense_stamps), &p, sizeof(p));
+}
+extern "C" int dfgnn_debug_set_wg_trace(void *p) {
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(dfgnn::dfgnn_wg_trace), &p, sizeof(p));
 }
 #endif

@@ -1295,6 +1295,38 @@ def test_harness_scripts_run_like_the_reference(capsys):
     assert "mismatch" not in out    # the reference's own verdict (DFGNN/utils/util.py:211-236), every format
 
 
+@pytest.mark.parametrize("h,f", [(8, 16), (4, 32), (2, 64), (2, 32), (12, 16), (4, 16)])
+def test_multihead_forward_takes_heads_in_groups(oracle_mod, h, f):
+    """Multi-head GT forward on the matrix cores (dfgnn_dense_heads.hpp: one workgroup per range, heads in groups of 64
+    feature columns): every range class in one batch -- <= 128 nodes (one strip per wave), 129..160 (two strips, images
+    fetched at the group boundary), > 160 (the per-head body), a 16-node graph, a strip with more edges than the per-wave
+    staging area holds (160 nodes at 95 % density) -- training (attn_edge written) and inference, against the oracle;
+    features of very different magnitude per head, so a group's shared image scale is exercised."""
+    import fused_gtconv as gt
+    from DFGNN.layers import preprocess_Hyper_fw_bw
+    from DFGNN.utils import synthetic as S
+    g = _dense_batch([(16, 0.6), (100, 0.45), (128, 0.5), (129, 0.4), (150, 0.45), (160, 0.95), (161, 0.3), (200, 0.3),
+                      (97, 0.1), (128, 1.0)], seed=4)
+    A, rows, row_ptr, col_ind, val, col_ptr, row_ind, val_idx, smem = preprocess_Hyper_fw_bw(g)
+    m = g.num_nodes()
+    Q, K, V = S.gt_features(m, h, f, seed=5, device=DEV)
+    mag = torch.logspace(-2, 2, h, device=DEV).view(1, h, 1)          # head k of V is 10^(4 k / (h - 1) - 2) times head 0's
+    V = (V * mag).contiguous()
+    K = (K * torch.logspace(0.5, -0.5, h, device=DEV).view(1, h, 1)).contiguous()
+    args = (row_ptr, col_ind, rows, val, col_ptr, row_ind, val_idx, smem, Q, K, V)
+    out, attn = gt.gt_hyper_forward(*args)
+    plan = row_ptr._dfgnn_plans[f]
+    assert plan.num_dense == plan.num_fit >= 9 and plan.num_spill == 0    # (the 16-node graph is merged with its neighbour)
+    n_ = lambda t: t.cpu().numpy()  # noqa: E731
+    want, want_attn = oracle_mod.gt_forward(n_(row_ptr), n_(col_ind), n_(val), n_(Q), n_(K), n_(V), want_attn=True)
+    _close(attn, want_attn, f"h={h} f={f} attn_edge")
+    inf = gt.gt_hyper_inference(row_ptr, col_ind, rows, val, smem, Q, K, V)[0]
+    for k in range(h):  # per head, in units of the head's own magnitude: the heads differ by four orders of magnitude
+        mk = float(mag[0, k, 0])
+        _close(out[:, k] / mk, want[:, k] / mk, f"h={h} f={f} out, head {k}")
+        _close(inf[:, k] / mk, want[:, k] / mk, f"h={h} f={f} inference, head {k}")
+
+
 @pytest.mark.parametrize("h,f", [(8, 16), (8, 8), (4, 16)])
 def test_multihead_small_width_on_matrix_cores(oracle_mod, h, f):
     """Multi-head GT with narrow heads (dim 128 / 8 heads, dim 64 / 8 heads): f = 16 and f = 8 run zero-padded on the
