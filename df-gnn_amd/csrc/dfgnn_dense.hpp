@@ -365,13 +365,24 @@ __device__ __forceinline__ void dense_store_rows(const f32x4 (&acc)[NFT], float 
   }
 }
 
+// All-reduce over the four lanes {mi, mi + 16, mi + 32, mi + 48} that hold one row of a D^T strip: two permlane swaps
+// (VALU rate) instead of two ds_bpermute round trips through the LDS crossbar.  swap32 of two copies leaves the lower
+// half's values in both halves of one and the upper half's in the other; swap16 does the same for the 16-lane rows.
 __device__ __forceinline__ float xor16_32_max(float v) {
-  v = fmaxf(v, __shfl_xor(v, 16));
-  return fmaxf(v, __shfl_xor(v, 32));
+  float a = v, b = v;
+  permlane32_swap(a, b);
+  a = fmaxf(a, b);
+  b = a;
+  permlane16_swap(a, b);
+  return fmaxf(a, b);
 }
 __device__ __forceinline__ float xor16_32_sum(float v) {
-  v += __shfl_xor(v, 16);
-  return v + __shfl_xor(v, 32);
+  float a = v, b = v;
+  permlane32_swap(a, b);
+  a += b;
+  b = a;
+  permlane16_swap(a, b);
+  return a + b;
 }
 
 }  // namespace dfgnn

@@ -81,6 +81,7 @@ __device__ __forceinline__ void dense_fwd_heads_body(float *lds, int lds_bytes, 
   const float *Qb = Q + (size_t)n0 * hf, *Kb = K + (size_t)n0 * hf, *Vb = V + (size_t)n0 * hf;
   float *Ob = out + (size_t)n0 * hf;
 
+  DFGNN_DSTAMP(0)
   // ---- prologue: every long-latency load goes out before the first barrier, the small ones first -----------------------
   int rp_mine = 0;
   {
@@ -152,6 +153,7 @@ __device__ __forceinline__ void dense_fwd_heads_body(float *lds, int lds_bytes, 
     lds_barrier();
   };
   images_commit(1);
+  DFGNN_DSTAMP(1)
   // the strips' rows of the byte map, for every head
   unsigned mw[NS][NT];
   int row_e0[NS], strip_e0[NS], strip_e1[NS];  // rp of this lane's row; edge range of the strip
@@ -201,6 +203,7 @@ __device__ __forceinline__ void dense_fwd_heads_body(float *lds, int lds_bytes, 
         }
         // the last head of the group has converted its Q: the raw rows of the next group can be requested
         if (q == G - 1 && s == NS - 1 && gq + 1 < ngroups) q_fetch(Qb + (gq + 1) * FW);
+        if (gq == 0 && q == 0 && s == 0) { DFGNN_DSTAMP(2) }
         if (strip < nstrip) {
           // One strip per wave: the compiler takes everything that depends only on the map words -- edge predicates, slots,
           // staging addresses -- out of the head loop (they are the same for every head), a welcome saving.  With two strips
@@ -228,6 +231,7 @@ __device__ __forceinline__ void dense_fwd_heads_body(float *lds, int lds_bytes, 
             }
             S[u] = acc;
           }
+          if (gq == 0 && q == 0 && s == 0) { DFGNN_DSTAMP(3) }
           // ---- masked row softmax in registers: the logits are S x c (c a power of two), the exponent is taken base 2 -
           const float c2 = (ksc.inv * qinv) * 1.4426950408889634f;
           float mx = -INFINITY;
@@ -253,6 +257,7 @@ __device__ __forceinline__ void dense_fwd_heads_body(float *lds, int lds_bytes, 
             }
           sum = xor16_32_sum(sum);
           const float inv = (sum != 0.f) ? 1.f / sum : 0.f;
+          if (gq == 0 && q == 0 && s == 0) { DFGNN_DSTAMP(4) }
           if constexpr (WRITE_ATTN) {
             float *dst = attn_edge + (size_t)head * g.nnz + e0;
             const int s0 = strip_e0[s], s1 = strip_e1[s];
@@ -271,7 +276,17 @@ __device__ __forceinline__ void dense_fwd_heads_body(float *lds, int lds_bytes, 
                 }
               }
               wave_sync();
-              for (int e = s0 + (int)(threadIdx.x & (kWave - 1)); e < s1; e += kWave) dst[e] = wstage[e - s0];
+              {  // four lines per trip: the LDS reads of a trip are issued together
+                const int l = (int)(threadIdx.x & (kWave - 1));
+                for (int e = s0 + l; e < s1; e += 4 * kWave) {
+                  float v[4];
+#pragma unroll
+                  for (int k = 0; k < 4; ++k) v[k] = wstage[min(e + k * kWave, s1 - 1) - s0];
+#pragma unroll
+                  for (int k = 0; k < 4; ++k)
+                    if (e + k * kWave < s1) dst[e + k * kWave] = v[k];
+                }
+              }
               wave_sync();  // (the area is reused by the wave's next strip / head)
             } else {  // a strip with more edges than the area holds: straight from the registers
               float *grow = dst + row_e0[s];
@@ -287,6 +302,7 @@ __device__ __forceinline__ void dense_fwd_heads_body(float *lds, int lds_bytes, 
               }
             }
           }
+          if (gq == 0 && q == 0 && s == 0) { DFGNN_DSTAMP(5) }
           // ---- O^T tiles of this head = V^T P^T: its FTH feature tiles of the group's V image ------------------------
           f32x4 acc[FTH], aux[2];
 #pragma unroll
@@ -310,8 +326,10 @@ __device__ __forceinline__ void dense_fwd_heads_body(float *lds, int lds_bytes, 
 #pragma unroll
           for (int k = 0; k < FTH; ++k) o[s][q * FTH + k] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
+        if (gq == 0 && q == 0 && s == 0) { DFGNN_DSTAMP(6) }
       }
     }
+    if (gq == 0) { DFGNN_DSTAMP(7) }
     // the group's 64 output columns of every row, as whole lines
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
@@ -319,13 +337,16 @@ __device__ __forceinline__ void dense_fwd_heads_body(float *lds, int lds_bytes, 
       if ((wave + 8 * s) * 16 < n)
         dense_store_rows<FT>(o[s], 1.f, Ob + gq * FW, (unsigned)hf, (wave + 8 * s) * 16 + L.mi, n, L);
     }
+    if (gq == 0) { DFGNN_DSTAMP(8) }
     if (gq + 1 >= ngroups) break;
     if constexpr (!kPrefetch) {
       dense_stage_load<FW, NP>(stK, Kb + (gq + 1) * FW, hf, 0, n);
       dense_stage_load<FW, NP>(stV, Vb + (gq + 1) * FW, hf, 0, n);
     }
     images_commit(gq + 2);
+    if (gq == 0) { DFGNN_DSTAMP(9) }
   }
+  DFGNN_DSTAMP(10)
 }
 
 }  // namespace dfgnn

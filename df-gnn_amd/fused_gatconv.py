@@ -5,7 +5,8 @@ MI355X HIP library through its C ABI (include/dfgnn.h).  See fused_gtconv.py for
 In scope: the four inference entry points of the hyper / softmax /
 softmax_gm / tiling variants, and the training pair gat_forward / gat_backward
 behind FusedGATFunction and (8f rank 3) the hyper_v2 / hyper_recompute entry points of the reference's comparison
-sweeps.  The tile-scheduler experiment gat_forward_tb raises NotImplementedError rather than pretending.
+sweeps.  gat_forward_tb (the reference's tile-scheduler experiment, no Python caller there) returns the same three
+tensors from the training forward; its schedule argument only distributes work and is validated, not followed.
 """
 import torch
 
@@ -155,15 +156,6 @@ def gat_inference_hyper_v2(smem_consume, a_l, a_r, indptr, indices, negative_slo
     return gat_inference_tiling(attn_row, attn_col, indptr, indices, negative_slope, in_feat)
 
 
-def _next(name):
-    def fn(*args, **kwargs):
-        raise NotImplementedError(
-            f"fused_gatconv.{name} is outside this build's hot-path scope (a tile-scheduler experiment of the "
-            "reference); use gat_forward / the hyper / softmax / softmax_gm / tiling entry points")
-    fn.__name__ = name
-    return fn
-
-
 def _train_plan(row_ptr, col_ind, f, attn_drop):
     """(rows, plan, meta) for the training pair: the block plan and the COO row ids when the batch may qualify for
     the matrix-core kernels (the library checks that every range of the plan is dense), else Nones."""
@@ -243,4 +235,16 @@ def gat_backward(negative_slope, attn_drop, row_ptr, col_ind, col_ptr, row_ind, 
     return [grad_feat, grad_attn_row, grad_attn_col]
 
 
-gat_forward_tb = _next("gat_forward_tb")
+def gat_forward_tb(attn_row, attn_col, row_ptr, col_ind, negative_slope, in_feat, tile_scheduler):
+    """fused_gatconv.cpp:256-282 -> [out_feat[m,h,f], edge_max[m,h], edge_sum[m,h]].
+
+    The reference's kernel (fused_gatconv_kernel.cu:976-1060) walks `tile_scheduler` -- int32 (row, 32-edge tile of the
+    row) pairs -- one workgroup per entry, and combines the tiles of a row through atomics on edge_max / edge_sum with
+    no grid-wide synchronisation (its result depends on workgroup timing).  The schedule only says who computes what;
+    the values it is meant to produce are those of gat_forward without dropout, which is what this returns (the MI355X
+    kernels split heavy rows themselves)."""
+    check_device(tile_scheduler=tile_scheduler, in_feat=in_feat)
+    check_contiguous(tile_scheduler=tile_scheduler)
+    check_dtype(torch.int32, tile_scheduler=tile_scheduler)
+    out, edge_max, edge_sum, _ = gat_forward(attn_row, attn_col, row_ptr, col_ind, negative_slope, in_feat, 0.0)
+    return [out, edge_max, edge_sum]

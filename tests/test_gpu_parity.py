@@ -628,6 +628,23 @@ def test_dense_kernels_every_geometry(oracle_mod, h, f):
     _close(gat.gat_inference_hyper(smem, ar, ac, row_ptr, col_ind, rows, 0.2, X), want_gat, "dense GAT hyper")
 
 
+def test_gat_forward_tb_returns_the_training_forward():
+    """fused_gatconv.gat_forward_tb (fused_gatconv.cpp:256-282): out / edge_max / edge_sum of the GAT forward, whatever
+    the tile schedule says about who computes which 32-edge tile."""
+    import fused_gatconv as gat
+    from DFGNN.utils import synthetic as S
+    from DFGNN.layers import preprocess_CSR
+    g = S.cora_like().to(DEV)
+    row_ptr, col_ind, _, _ = preprocess_CSR(g)
+    m = g.num_nodes()
+    ar, ac, X = S.gat_features(m, 2, 32, seed=2, device=DEV)
+    deg = (row_ptr[1:] - row_ptr[:-1]).cpu().numpy()
+    sched = np.array([(r, t) for r in range(m) for t in range((int(deg[r]) + 31) // 32)], dtype=np.int32)
+    out, mx, sm = gat.gat_forward_tb(ar, ac, row_ptr, col_ind, 0.2, X, torch.from_numpy(sched).to(DEV))
+    ref = gat.gat_forward(ar, ac, row_ptr, col_ind, 0.2, X, 0.0)
+    assert torch.equal(out, ref[0]) and torch.equal(mx, ref[1]) and torch.equal(sm, ref[2])
+
+
 def _dense_batch(sizes, seed):
     """Block-diagonal batch of symmetric Erdos-Renyi graphs, given as (nodes, edge probability) pairs (every range
     dense, no duplicates)."""

@@ -84,8 +84,8 @@ def test_binding_rejects_cpu_tensors_and_bad_dtypes():
         fused_gatconv.gat_inference_hyper_v2(1024, a, a, ip, idx, 0.2, q)
     with pytest.raises(RuntimeError, match="must be on CUDA"):
         fused_gatconv.gat_inference_hyper_recompute(a, a, ip, idx, 0.2, q)
-    with pytest.raises(NotImplementedError):                        # the tile-scheduler experiment stays out of scope
-        fused_gatconv.gat_forward_tb(a, a, ip, idx, 0.2, q, None)
+    with pytest.raises(RuntimeError, match="must be on CUDA"):       # the tile-scheduler entry point: same forward
+        fused_gatconv.gat_forward_tb(a, a, ip, idx, 0.2, q, torch.zeros(1, 2, dtype=torch.int32))
 
 
 def _args(conv, fmt, dim, heads):
