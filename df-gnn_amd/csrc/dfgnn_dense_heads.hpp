@@ -350,3 +350,304 @@ __device__ __forceinline__ void dense_fwd_heads_body(float *lds, int lds_bytes, 
 }
 
 }  // namespace dfgnn
+
+namespace dfgnn {
+
+// =====================================================================================================================
+// backward, every head of a range of <= 128 nodes in one workgroup
+// =====================================================================================================================
+// The per-(range, head) backward (gt_dense.hip: dense_bwd_body) starts cold for every head -- edge coordinates,
+// attention values and the dO image have to arrive before anything can be done (a quarter of its time for 16-wide
+// heads) -- and swaps one image buffer four times per head, a barrier pair each.  Here a workgroup walks the heads of
+// its range:
+//   * the edge coordinates are fetched once (registers) and reused by every head's scatter;
+//   * TWO image buffers: dO and V are resident together (dV^T = dO^T P and dP = dO V^T need no barrier between them),
+//     then K and Q (dQ = dS K and dK^T = Q^T dS likewise); four barriers per head;
+//   * the next pair of images and the next head's attention values travel in registers while the current pair is used;
+//   * the tile is never cleared after the first head: dS is exactly zero where P is, so the pairs that are no edge
+//     already hold zeros when the next head's P values are scattered onto the (identical) edge positions.
+// P and dS live in the tile as interleaved fp16 hi | lo rows (dfgnn_dense_wide.hpp's form: P under the constant scale
+// 2^14, dS under the tile's power-of-two scale).  Same numerics and operand layouts as dfgnn_dense.hpp.
+// Replaces, for such ranges, fused_gtconv_backward.cu:40-191 (which is single-head only).
+// dense_stage_store / dense_rows_mma_strip with the image row stride as a parameter (the 160-row walk uses a tighter
+// one than dfgnn_dense.hpp's F + 16 to fit two images next to its tile)
+template <int F, int ROWS, int RS>
+__device__ __forceinline__ void dense_stage_store_rs(DenseStageRegs<F, ROWS> &r, h16 *hi, h16 *lo, float scale, int fr) {
+  constexpr int C8 = F / 8;
+  const int tid = opaque_tid();
+#pragma unroll
+  for (int k = 0; k < DenseStageRegs<F, ROWS>::PER; ++k) {
+    const int idx = tid + k * kDenseThreads;
+    const int row = idx / C8, c8 = idx - row * C8;
+    if (idx < ROWS * C8) {
+      const bool valid = r.row0 + row < r.row_end && (fr >= F || 8 * c8 < fr);
+      const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+      hx8 h, l;
+      split_hx8(valid ? r.a[k] : z, valid ? r.b[k] : z, scale, h, l);
+      *reinterpret_cast<hx8 *>(hi + row * RS + 8 * c8) = h;
+      *reinterpret_cast<hx8 *>(lo + row * RS + 8 * c8) = l;
+    }
+  }
+  asm volatile("" ::: "memory");
+}
+template <int F, int NTILES, int RS>
+__device__ __forceinline__ void dense_rows_mma_strip_rs(f32x4 (&out)[NTILES], const h16 *ihi, const h16 *ilo, int limit,
+                                                        const hx8 (&xh)[F / 32], const hx8 (&xl)[F / 32], const LaneIds &L) {
+#pragma unroll
+  for (int u = 0; u < NTILES; ++u) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (16 * u < limit) {
+      const int off = (16 * u + L.mi) * RS + 8 * L.mq;
+#pragma unroll
+      for (int t = 0; t < F / 32; ++t) {
+        const hx8 ah = *reinterpret_cast<const hx8 *>(ihi + off + 32 * t), al = *reinterpret_cast<const hx8 *>(ilo + off + 32 * t);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, xh[t], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, xl[t], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, xh[t], acc, 0, 0, 0);
+      }
+    }
+    out[u] = acc;
+  }
+}
+
+template <int FR, int NP = 128>
+__device__ __forceinline__ void dense_bwd_heads_body(float *lds, const Csr &g, int n0, int n, int e0, int ne, int head0,
+                                                     int nheads, const float *__restrict__ Q, const float *__restrict__ K,
+                                                     const float *__restrict__ V, const float *__restrict__ attn_edge,
+                                                     const float *__restrict__ dO, float *__restrict__ dQ,
+                                                     float *__restrict__ dK, float *__restrict__ dV) {
+  constexpr int F = FR < 32 ? 32 : FR, U = NP / 16, NS = (U + kDenseWaves - 1) / kDenseWaves, PRE = kDensePre;
+  constexpr int fr = FR;
+  using D = DenseCfg<F>;
+  // image row stride: F + 16 elements (conflict-free row and transposed reads) when two images fit next to the tile that
+  // way, else F + 8 (160 rows: some two-way conflicts in the transposed reads, but no third and fourth barrier pair)
+  constexpr int RS = (NP > 128) ? F + 8 : D::RS, KT = D::KT, FT = D::FT, TS = NP + 8, TB = 2 * TS;
+  static_assert(NP == 128 || F == 32, "the 160-row walk is for heads of at most 32 features");
+  static_assert((4 * NP * RS + NP * TB) * 2 + 3 * kDenseWaves * 4 <= kLdsBytes, "LDS");
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+  const int nstrip = (n + 15) >> 4;
+  h16 *ahi = reinterpret_cast<h16 *>(lds), *alo = ahi + (size_t)NP * RS;   // buffer A: dO, then K
+  h16 *bhi = alo + (size_t)NP * RS, *blo = bhi + (size_t)NP * RS;         // buffer B: V, then Q
+  h16 *Tb = blo + (size_t)NP * RS;                                        // the tile: NP rows of hi[TS] | lo[TS]
+  float *smax = reinterpret_cast<float *>(Tb + (size_t)NP * TB);          // [3][8] per-wave maxima: image A, image B, dS
+  const size_t hf = (size_t)g.h * fr;
+  const float *Qb = Q + (size_t)n0 * hf, *Kb = K + (size_t)n0 * hf, *Vb = V + (size_t)n0 * hf, *dOb = dO + (size_t)n0 * hf;
+  float *dQb = dQ + (size_t)n0 * hf, *dKb = dK + (size_t)n0 * hf, *dVb = dV + (size_t)n0 * hf;
+  const float *attn0 = attn_edge + e0;
+  const int hend = head0 + nheads;  // this workgroup walks the heads head0 .. hend - 1
+
+  // ---- prologue: coordinates (kept), the first head's attention values, dO and V images -------------------------------
+  unsigned pc[PRE];
+  float pa[PRE];
+  auto attn_fetch = [&](const float *attn_h) {
+    const int tid = opaque_tid();
+#pragma unroll
+    for (int k = 0; k < PRE; ++k) pa[k] = ld32(attn_h, (unsigned)min(tid + k * kDenseThreads, max(ne, 1) - 1));
+  };
+  {
+    const int tid = opaque_tid();
+#pragma unroll
+    for (int k = 0; k < PRE; ++k) pc[k] = ld32(g.coords + e0, (unsigned)min(tid + k * kDenseThreads, max(ne, 1) - 1));
+  }
+  attn_fetch(attn0 + (size_t)head0 * g.nnz);
+  DenseStageRegs<F, NP> stA, stB;
+  dense_stage_load<F, NP>(stA, dOb + head0 * fr, hf, 0, n, fr);
+  dense_stage_load<F, NP>(stB, Vb + head0 * fr, hf, 0, n, fr);
+  {
+    const int tid = opaque_tid();
+    for (int k = tid; k < NP * TB / 8; k += kDenseThreads) reinterpret_cast<float4 *>(Tb)[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  wg_max_post(smax, dense_stage_absmax<F, NP>(stA));
+  wg_max_post(smax + kDenseWaves, dense_stage_absmax<F, NP>(stB));
+  lds_barrier();
+
+  // P of every edge -> the tile, fp16 hi | lo under the scale 2^14 (the edges past the prefetched ones from memory)
+  auto scatter = [&](const float *attn_h) {
+    const int tid = opaque_tid();
+    auto put = [&](unsigned c, float p) {
+      const int at = (int)(c >> 8) * TB + (int)(c & 0xFF);
+      const h16 hh = (h16)(p * kUnitScale);
+      Tb[at] = hh;
+      Tb[at + TS] = (h16)fmaf(p, kUnitScale, -(float)hh);
+    };
+#pragma unroll
+    for (int k = 0; k < PRE; ++k)
+      if (tid + k * kDenseThreads < ne) put(pc[k], pa[k]);
+    for (int e = tid + PRE * kDenseThreads; e < ne; e += kDenseThreads) put(g.coords[e0 + e], attn_h[e]);
+  };
+  // out^T[f][c] = sum_i X[i][f] Y[i][c]: X = an image, Y = the tile.  Column strip cs, all FT feature tiles (ft < 0: the
+  // tile fragments are shared) or the single feature tile ft
+  auto column_unit = [&](const h16 *xhi, const h16 *xlo, float *outb, int cs, int ft, float oscale) {
+    const LaneIds L = lane_ids();
+    const int j = cs * 16 + L.mi;
+    if (ft < 0) {
+      f32x4 acc[FT];
+#pragma unroll
+      for (int t = 0; t < FT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ib = 0; ib < NP / 32; ++ib) {
+        if (32 * ib < n) {
+          const int yoff = (32 * ib + 4 * L.mq + L.tq) * TB + 16 * cs + 4 * L.tp;
+          const hx8 yh = dense_tr_pair(Tb + yoff, 16 * TB);
+          const hx8 yl = dense_tr_pair(Tb + yoff + TS, 16 * TB);
+          dense_kblock_mma<F, 4>(acc, xhi, xlo, (32 * ib + 4 * L.mq + L.tq) * RS + 4 * L.tp, 16 * RS, yh, yl);
+        }
+      }
+      if constexpr (FR == F) dense_store_rows<FT>(acc, oscale, outb, (unsigned)hf, j, n, L);
+      else if (j < n) dense_store_acc<FT, true>(acc, oscale, outb, (unsigned)j * (unsigned)hf + 4u * L.mq, false, 4 * L.mq, fr);
+    } else {
+      f32x4 acc[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+      for (int ib = 0; ib < NP / 32; ++ib) {
+        if (32 * ib < n) {
+          const int yoff = (32 * ib + 4 * L.mq + L.tq) * TB + 16 * cs + 4 * L.tp;
+          const hx8 yh = dense_tr_pair(Tb + yoff, 16 * TB);
+          const hx8 yl = dense_tr_pair(Tb + yoff + TS, 16 * TB);
+          const int xoff = (32 * ib + 4 * L.mq + L.tq) * RS + 4 * L.tp + 16 * ft;
+          const hx8 xh = dense_tr_pair(xhi + xoff, 16 * RS);
+          const hx8 xl = dense_tr_pair(xlo + xoff, 16 * RS);
+          acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh, yh, acc[0], 0, 0, 0);
+          acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xl, yh, acc[0], 0, 0, 0);
+          acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh, yl, acc[0], 0, 0, 0);
+        }
+      }
+      if (j < n)
+        dense_store_acc<1, (FR < F)>(acc, oscale, outb, (unsigned)j * (unsigned)hf + 16u * ft + 4u * L.mq, false, 16 * ft + 4 * L.mq, fr);
+    }
+  };
+  // all column strips of the range: the first eight whole, the others dealt out tile by tile so that all waves share them
+  auto column_phase = [&](const h16 *xhi, const h16 *xlo, float *outb, float oscale) {
+    if (wave < nstrip) column_unit(xhi, xlo, outb, wave, -1, oscale);
+    if constexpr (NS > 1)
+      for (int unit = wave; unit < (nstrip - kDenseWaves) * FT; unit += kDenseWaves)
+        column_unit(xhi, xlo, outb, kDenseWaves + unit / FT, unit % FT, oscale);
+  };
+
+  for (int hd = head0;; ++hd) {  // ---- one head per trip --------------------------------------------------------------------
+    const unsigned hoff = (unsigned)hd * fr;
+    // images: dO -> A, V -> B (their maxima were posted ahead of the last barrier); tile := P
+    const Pow2Scale dosc = pow2_scale(wg_max_read(smax)), vsc = pow2_scale(wg_max_read(smax + kDenseWaves));
+    dense_stage_store_rs<F, NP, RS>(stA, ahi, alo, dosc.s, fr);
+    dense_stage_store_rs<F, NP, RS>(stB, bhi, blo, vsc.s, fr);
+    dense_stage_load<F, NP>(stA, Kb + hoff, hf, 0, n, fr);  // the next pair: K, Q of this head
+    dense_stage_load<F, NP>(stB, Qb + hoff, hf, 0, n, fr);
+    scatter(attn0 + (size_t)hd * g.nnz);
+    lds_barrier();  // B0
+    if (hd + 1 < hend) attn_fetch(attn0 + (size_t)(hd + 1) * g.nnz);  // (the values of this head are in the tile)
+
+    // ---- dP^T = V dO^T ; t ; dS (registers) ; dV^T = dO^T P ----------------------------------------------------------
+    f32x4 dS[NS][U];
+    float tmax = 0.f;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const int strip = wave + kDenseWaves * s;
+      if (strip < nstrip) {
+        const LaneIds L = lane_ids();
+        hx8 gh[KT], gl[KT];  // this strip's dO rows: the register operand of dP (the image's scale)
+        const int off = (strip * 16 + L.mi) * RS + 8 * L.mq;
+#pragma unroll
+        for (int t = 0; t < KT; ++t) {
+          gh[t] = *reinterpret_cast<const hx8 *>(ahi + off + 32 * t);
+          gl[t] = *reinterpret_cast<const hx8 *>(alo + off + 32 * t);
+        }
+        f32x4 Pr[U];
+        const h16 *trow = Tb + (strip * 16 + L.mi) * TB + 4 * L.mq;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const hx4 h4 = *reinterpret_cast<const hx4 *>(trow + 16 * u), l4 = *reinterpret_cast<const hx4 *>(trow + TS + 16 * u);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) Pr[u][r] = ((float)h4[r] + (float)l4[r]) * kUnitScaleInv;
+        }
+        dense_rows_mma_strip_rs<F, U, RS>(dS[s], bhi, blo, n, gh, gl, L);  // dP (x the two scales)
+        const float dpinv = vsc.inv * dosc.inv;
+        float t = 0.f;
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            dS[s][u][r] *= dpinv;
+            t = fmaf(Pr[u][r], dS[s][u][r], t);
+          }
+        t = xor16_32_sum(t);  // a row lives on 4 lanes of this wave
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            dS[s][u][r] = Pr[u][r] * (dS[s][u][r] - t);
+            tmax = fmaxf(tmax, fabsf(dS[s][u][r]));
+          }
+      } else {
+#pragma unroll
+        for (int u = 0; u < U; ++u) dS[s][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+    column_phase(ahi, alo, dVb + hoff, dosc.inv * kUnitScaleInv);
+    wg_max_post(smax, dense_stage_absmax<F, NP>(stA));                 // K
+    wg_max_post(smax + kDenseWaves, dense_stage_absmax<F, NP>(stB));   // Q
+    wg_max_post(smax + 2 * kDenseWaves, tmax);
+    lds_barrier();  // B1: every wave is done with the P tile and the dO / V images
+
+    // ---- tile := dS ; images: K -> A, Q -> B ; dQ = dS K ; dK^T = Q^T dS ----------------------------------------------
+    const Pow2Scale ksc = pow2_scale(wg_max_read(smax)), qsc = pow2_scale(wg_max_read(smax + kDenseWaves));
+    const Pow2Scale ts = pow2_scale(wg_max_read(smax + 2 * kDenseWaves));
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const int strip = wave + kDenseWaves * s;
+      if (strip < nstrip) {
+        const LaneIds L = lane_ids();
+        h16 *trow = Tb + (strip * 16 + L.mi) * TB + 4 * L.mq;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          hx4 h4, l4;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const h16 hh = (h16)(dS[s][u][r] * ts.s);
+            h4[r] = hh;
+            l4[r] = (h16)fmaf(dS[s][u][r], ts.s, -(float)hh);
+          }
+          *reinterpret_cast<hx4 *>(trow + 16 * u) = h4;
+          *reinterpret_cast<hx4 *>(trow + TS + 16 * u) = l4;
+        }
+      }
+    }
+    dense_stage_store_rs<F, NP, RS>(stA, ahi, alo, ksc.s, fr);
+    dense_stage_store_rs<F, NP, RS>(stB, bhi, blo, qsc.s, fr);
+    const bool more = hd + 1 < hend;
+    {  // the next head's dO and V (after the last head: one clamped row each, cache hits, never stored)
+      const unsigned noff = more ? hoff + fr : hoff;
+      dense_stage_load<F, NP>(stA, dOb + noff, hf, 0, more ? n : 1, fr);
+      dense_stage_load<F, NP>(stB, Vb + noff, hf, 0, more ? n : 1, fr);
+    }
+    lds_barrier();  // B2
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const int strip = wave + kDenseWaves * s;
+      if (strip < nstrip) {
+        const LaneIds L = lane_ids();
+        f32x4 qacc[FT];
+#pragma unroll
+        for (int ft = 0; ft < FT; ++ft) qacc[ft] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const h16 *srow = Tb + (strip * 16 + L.mi) * TB + 8 * L.mq;
+#pragma unroll
+        for (int jb = 0; jb < NP / 32; ++jb) {
+          if (32 * jb < n) {
+            // natural k order: element t of lane (mi, mq) is column 32 jb + 8 mq + t of dS / that row of K
+            const hx8 sh = *reinterpret_cast<const hx8 *>(srow + 32 * jb);
+            const hx8 sl = *reinterpret_cast<const hx8 *>(srow + TS + 32 * jb);
+            dense_kblock_mma<F, 4>(qacc, ahi, alo, (32 * jb + 8 * L.mq + L.tq) * RS + 4 * L.tp, 4 * RS, sh, sl);
+          }
+        }
+        const int i = strip * 16 + L.mi;
+        if constexpr (FR == F) dense_store_rows<FT>(qacc, ksc.inv * ts.inv, dQb + hoff, (unsigned)hf, i, n, L);
+        else if (i < n) dense_store_acc<FT, true>(qacc, ksc.inv * ts.inv, dQb + hoff, (unsigned)i * (unsigned)hf + 4u * L.mq, false, 4 * L.mq, fr);
+      }
+    }
+    column_phase(bhi, blo, dKb + hoff, qsc.inv * ts.inv);
+    if (!more) break;
+    wg_max_post(smax, dense_stage_absmax<F, NP>(stA));                 // dO of the next head
+    wg_max_post(smax + kDenseWaves, dense_stage_absmax<F, NP>(stB));   // V
+    lds_barrier();  // B3: every wave is done with the dS tile and the K / Q images
+  }
+}
+
+}  // namespace dfgnn

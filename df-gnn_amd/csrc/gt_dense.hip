@@ -1101,11 +1101,38 @@ template <int F>
 __global__ __launch_bounds__(kDenseThreads) void gt_dense_bwd_kernel(
     Csr g, const int *__restrict__ fit, const float *__restrict__ Q, const float *__restrict__ K,
     const float *__restrict__ V, const float *__restrict__ attn_edge, const float *__restrict__ dO,
-    float *__restrict__ dQ, float *__restrict__ dK, float *__restrict__ dV) {
+    float *__restrict__ dQ, float *__restrict__ dK, float *__restrict__ dV, int heads_from, int walk) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   DFGNN_TRACE_IN
-  const int n0 = fit[2 * blockIdx.x], n1 = fit[2 * blockIdx.x + 1] & kPlanRangeMask;
+  // heads_from < 0: grid (ranges, heads), one workgroup per (range, head).  heads_from >= 0 (multi-head, heads of at
+  // most 64 features): a 1-D grid -- the first heads_from ranges (those of more than 128 nodes: they come first in the
+  // plan) still get one workgroup per head, every other range ceil(h / walk) workgroups that walk `walk` heads each
+  // (dfgnn_dense_heads.hpp).  The 129..160-node ranges stay per head: walked (the body takes NP = 160 for heads of at
+  // most 32 features) their workgroups are 8 heads long, 312 of them on 256 CUs, and the kernel waits for the second
+  // round -- measured 379 us (8 heads) / 223 us (4 heads) against 387 / 210 us per head.
+  // (Workgroups go to the XCDs round-robin by index: the per-head index is range * h + head, so all heads are spread.)
+  int range = blockIdx.x, head = blockIdx.y, nwalk = 0;
+  if (heads_from >= 0) {
+    const int w = blockIdx.x;
+    if (w < heads_from * g.h) {
+      range = w / g.h;
+      head = w - range * g.h;
+    } else {
+      const int chunks = (g.h + walk - 1) / walk, k = w - heads_from * g.h;
+      range = heads_from + k / chunks;
+      head = (k % chunks) * walk;
+      nwalk = min(walk, g.h - head);
+    }
+  }
+  const int n0 = fit[2 * range], n1 = fit[2 * range + 1] & kPlanRangeMask;
   const int n = n1 - n0, e0 = g.row_ptr[n0], ne = g.row_ptr[n1] - e0;
+  if constexpr (F <= 64) {
+    if (nwalk > 0) {  // (n <= 128 by construction)
+      dense_bwd_heads_body<F>(lds, g, n0, n, e0, ne, head, nwalk, Q, K, V, attn_edge, dO, dQ, dK, dV);
+      DFGNN_TRACE_OUT
+      return;
+    }
+  }
 #ifdef DFGNN_BWD_VARIANT  // diagnostic builds: one geometry only (register use / ISA of a single body)
   constexpr int only = DFGNN_BWD_VARIANT;
 #else
@@ -1113,18 +1140,18 @@ __global__ __launch_bounds__(kDenseThreads) void gt_dense_bwd_kernel(
 #endif
   if ((only < 0 && n <= kDenseChunkRows) || only == 0)
 #ifdef DFGNN_RING128  // A/B builds: half-width images through the prefetch ring for the <= 128-node ranges as well
-    dense_bwd_wide_body<F, kDenseChunkRows, DFGNN_RING128, DFGNN_FW128>(lds, g, n0, n, e0, ne, blockIdx.y, Q, K, V, attn_edge, dO, dQ, dK, dV);
+    dense_bwd_wide_body<F, kDenseChunkRows, DFGNN_RING128, DFGNN_FW128>(lds, g, n0, n, e0, ne, head, Q, K, V, attn_edge, dO, dQ, dK, dV);
 #else
-    dense_bwd_body<F, kDenseChunkRows, 1>(lds, g, n0, n, e0, ne, blockIdx.y, Q, K, V, attn_edge, dO, dQ, dK, dV);
+    dense_bwd_body<F, kDenseChunkRows, 1>(lds, g, n0, n, e0, ne, head, Q, K, V, attn_edge, dO, dQ, dK, dV);
 #endif
   else if ((only < 0 && n <= kDenseWideRows) || only == 1)
 #ifdef DFGNN_OLD_WIDE_BWD  // A/B builds only: two row blocks of <= 80 rows, full-width images
-    dense_bwd_body<F, kDenseWideRows, 1>(lds, g, n0, n, e0, ne, blockIdx.y, Q, K, V, attn_edge, dO, dQ, dK, dV);
+    dense_bwd_body<F, kDenseWideRows, 1>(lds, g, n0, n, e0, ne, head, Q, K, V, attn_edge, dO, dQ, dK, dV);
 #else
-    dense_bwd_wide_body<F, kDenseWideRows, DFGNN_RING160>(lds, g, n0, n, e0, ne, blockIdx.y, Q, K, V, attn_edge, dO, dQ, dK, dV);
+    dense_bwd_wide_body<F, kDenseWideRows, DFGNN_RING160>(lds, g, n0, n, e0, ne, head, Q, K, V, attn_edge, dO, dQ, dK, dV);
 #endif
   else
-    dense_bwd_body<F, kDenseChunkRows, 2>(lds, g, n0, n, e0, ne, blockIdx.y, Q, K, V, attn_edge, dO, dQ, dK, dV);
+    dense_bwd_body<F, kDenseChunkRows, 2>(lds, g, n0, n, e0, ne, head, Q, K, V, attn_edge, dO, dQ, dK, dV);
   DFGNN_TRACE_OUT
 #ifdef DFGNN_STAMPS
   if (threadIdx.x == 0 && dfgnn_dense_stamps)
@@ -1148,6 +1175,14 @@ static int dispatch_dense(int f, Fn &&fn) {
   if (f == 64) return fn(std::integral_constant<int, 64>{});
   if (f == 128) return fn(std::integral_constant<int, 128>{});
   return kErrUnsupported;
+}
+
+// Heads a workgroup of the multi-head backward walks (ranges of <= 128 nodes): all of them (8 heads of 16: 393 us with
+// 8, 397 with 4, 408 with 2 heads per workgroup, 439 per head).  DFGNN_HEADS_WALK in the environment (diagnostic switch,
+// read once) overrides it; 0 = one workgroup per (range, head) throughout.
+static int heads_walk() {
+  static const int w = [] { const char *e = getenv("DFGNN_HEADS_WALK"); return e ? max(0, atoi(e)) : 64; }();
+  return w;
 }
 
 // DFGNN_LEAN=0 in the environment (diagnostic switch, read once): every dense range on the 512-thread forward
@@ -1244,11 +1279,16 @@ int launch_gt_dense_bwd(const Csr &g_in, const Plan &p, const float *Q, const fl
   Csr g = g_in;
   g.coords = p.coords();
   if (p.num_dense == 0) return 0;
-  const dim3 grid(p.num_dense, g.h);
+  // multi-head, heads of at most 64 features: one workgroup per range of <= 128 nodes walks the heads (see the kernel)
+  const int walk = (g.h > 1 && g.f <= 64) ? min(heads_walk(), g.h) : 0;
+  const int heads_from = walk ? p.num_dense_wide : -1;
+  const int chunks = walk ? (g.h + walk - 1) / walk : 0;
+  const dim3 grid = walk ? dim3(p.num_dense_wide * g.h + (p.num_dense - p.num_dense_wide) * chunks, 1) : dim3(p.num_dense, g.h);
   return dispatch_dense(g.f, [&](auto fc) {
     constexpr int F = decltype(fc)::value;
     if (int rc = set_max_lds(gt_dense_bwd_kernel<F>)) return rc;
-    gt_dense_bwd_kernel<F><<<grid, kDenseThreads, kLdsBytes, s>>>(g, p.fit(), Q, K, V, attn_edge, grad_out, dQ, dK, dV);
+    gt_dense_bwd_kernel<F><<<grid, kDenseThreads, kLdsBytes, s>>>(g, p.fit(), Q, K, V, attn_edge, grad_out, dQ, dK, dV,
+                                                                  heads_from, walk);
     return launch_status();
   });
 }

@@ -1342,6 +1342,17 @@ def test_multihead_forward_takes_heads_in_groups(oracle_mod, h, f):
         mk = float(mag[0, k, 0])
         _close(out[:, k] / mk, want[:, k] / mk, f"h={h} f={f} out, head {k}")
         _close(inf[:, k] / mk, want[:, k] / mk, f"h={h} f={f} inference, head {k}")
+    # backward: ranges of <= 128 nodes take one workgroup that walks the heads (two image buffers, the tile cleared once:
+    # dS is zero wherever P is), the larger ones one workgroup per head -- against the oracle and against the
+    # per-(range, head) form of the same kernels
+    Q, K, V = S.gt_features(m, h, f, seed=6, device=DEV)
+    dO = torch.randn(m, h, f, generator=torch.Generator().manual_seed(8)).to(DEV)
+    args = (row_ptr, col_ind, rows, val, col_ptr, row_ind, val_idx, smem, Q, K, V)
+    out, attn = gt.gt_hyper_forward(*args)
+    dQ, dK, dV = gt.gt_backward(*args, attn, dO)
+    wq, wk, wv = oracle_mod.gt_backward(n_(row_ptr), n_(col_ind), n_(val), n_(Q), n_(K), n_(V), n_(dO))
+    for got, ref, what in ((dQ, wq, "dQ"), (dK, wk, "dK"), (dV, wv, "dV")):
+        _close(got, ref, f"h={h} f={f} {what}")
 
 
 @pytest.mark.parametrize("h,f", [(8, 16), (8, 8), (4, 16)])

@@ -12,17 +12,19 @@ from DFGNN.layers import preprocess_Hyper_fw_bw
 from DFGNN.utils import synthetic as S
 dev = "cuda:0"
 bs = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+H = int(os.environ.get("HEADS", "1"))   # HEADS=8: dim 128 as 8 heads of 16 (backward: one workgroup per (range, head))
+FH = 128 // H
 g = S.pattern_like(batch_size=bs, seed=1).to(dev)
 A, rows, row_ptr, col_ind, val, col_ptr, row_ind, val_idx, smem = preprocess_Hyper_fw_bw(g)
 m = g.num_nodes()
-Q, K, V = S.gt_features(m, 1, 128, seed=100, device=dev)
+Q, K, V = S.gt_features(m, H, FH, seed=100, device=dev)
 L = dfgnn_native.lib()
 L.dfgnn_debug_set_dense_stamps.argtypes = [ctypes.c_void_p]
 args = (row_ptr, col_ind, rows, val, col_ptr, row_ind, val_idx, smem, Q, K, V)
 for _ in range(3):
     out, attn = gt.gt_hyper_forward(*args)
-plan = row_ptr._dfgnn_plans[128]
-nd = plan.num_dense
+plan = row_ptr._dfgnn_plans[FH]
+nd = plan.num_dense * H   # (stamp rows: one per workgroup)
 print("plan", plan.meta)
 e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
 
