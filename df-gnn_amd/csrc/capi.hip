@@ -10,9 +10,14 @@ inline hipStream_t as_stream(dfgnn_stream_t s) { return reinterpret_cast<hipStre
 
 // A plan is used only if it was built for exactly this (m, nnz, f) and LDS budget; otherwise the call
 // silently takes the general kernels (same results, no LDS residency).
-inline bool make_plan(Plan &p, const int *plan_dev, const int *meta, int m, int nnz, int f) {
+// The plan kernels (LDS-resident and matrix-core) address a feature row with 32-bit byte offsets; the general kernels
+// use size_t throughout.  Feature matrices of 4 GiB or more therefore take the general kernels.
+inline bool plan_offsets_fit(int m, int h, int f) { return (size_t)m * (size_t)h * (size_t)f * 4u < (1ull << 32); }
+
+inline bool make_plan(Plan &p, const int *plan_dev, const int *meta, int m, int nnz, int h, int f) {
   p = Plan{nullptr, 0, 0, 0, 0, m, nnz, f, 0, 0};
   if (!plan_dev || !meta) return false;
+  if (!plan_offsets_fit(m, h, f)) return false;
   if (meta[4] != m || meta[5] != nnz || meta[6] != f || meta[7] != kBlockLdsBudget) return false;
   if (meta[0] <= 0) return false;
   // Low-degree batches (e.g. molecule / peptide graphs, ~2 edges per row) are bound by the node features, not
@@ -46,6 +51,12 @@ extern "C" {
 
 int dfgnn_abi_version(void) { return DFGNN_ABI_VERSION; }
 
+int dfgnn_plan_applies(int m, int nnz, int h, int f, const int *plan_meta) {
+  Plan p;
+  static const int token = 0;  // (make_plan only stores the device pointer)
+  return make_plan(p, &token, plan_meta, m, nnz, h, f) ? 1 : 0;
+}
+
 #ifndef DFGNN_SRC_HASH
 #define DFGNN_SRC_HASH "unknown"
 #endif
@@ -69,7 +80,7 @@ int dfgnn_gt_hyper_fwd(int m, int nnz, int h, int f, const int *row_ptr, const i
   const Csr g{m, nnz, h, f, row_ptr, col_ind, rows, val};
   Plan p;
   const bool v4 = (f % 4 == 0) && aligned16(Q) && aligned16(K) && aligned16(V) && aligned16(out);
-  if (v4 && make_plan(p, plan, plan_meta, m, nnz, f) && plan_usable(p, f, !val, rows)) {
+  if (v4 && make_plan(p, plan, plan_meta, m, nnz, h, f) && plan_usable(p, f, !val, rows)) {
     if (int rc = launch_gt_block_fwd(g, p, Q, K, V, attn_edge, edge_ws, out, as_stream(stream))) return rc;
     return launch_gt_hyper_fwd(g, Q, K, V, attn_edge, out, p.spill(), p.num_spill, as_stream(stream));
   }
@@ -114,7 +125,7 @@ int dfgnn_gt_bwd(int m, int nnz, int h, int f, const int *row_ptr, const int *co
                   aligned16(dQ) && aligned16(dK) && aligned16(dV);
   const int *chunks = nullptr;
   int nchunks = 0;
-  if (v4 && make_plan(p, plan, plan_meta, m, nnz, f) && plan_usable(p, f, !val, rows)) {
+  if (v4 && make_plan(p, plan, plan_meta, m, nnz, h, f) && plan_usable(p, f, !val, rows)) {
     if (int rc = launch_gt_block_bwd(g, p, col_ptr, row_ind, val_idx, Q, K, V, attn_edge, grad_out, grad_edge, dQ,
                                      dK, dV, as_stream(stream)))
       return rc;
@@ -197,7 +208,7 @@ int dfgnn_gat_hyper_fwd(int m, int nnz, int h, int f, const int *row_ptr, const 
   const Csr g{m, nnz, h, f, row_ptr, col_ind, rows, nullptr};
   Plan p;
   const bool v4 = (f % 4 == 0) && aligned16(X) && aligned16(out);
-  if (v4 && make_plan(p, plan, plan_meta, m, nnz, f) && plan_usable(p, f, true, rows)) {
+  if (v4 && make_plan(p, plan, plan_meta, m, nnz, h, f) && plan_usable(p, f, true, rows)) {
     if (int rc = launch_gat_block_fwd(g, p, attn_row, attn_col, negative_slope, X, edge_ws, out, as_stream(stream)))
       return rc;
     return launch_gat_hyper_fwd(g, attn_row, attn_col, negative_slope, X, out, p.spill(), p.num_spill,
@@ -250,11 +261,11 @@ int dfgnn_gat_attn_scores(int m, int h, int f, const float *a_l, const float *a_
 
 // The GAT training pair serves the dense ranges of a plan with the matrix-core kernels and everything else (its
 // non-dense fit ranges, its spill chunks) with the general kernels restricted to those ranges.
-static bool gat_train_dense(Plan &p, const int *rows, const int *plan, const int *plan_meta, int m, int nnz, int f,
-                            bool v4) {
+static bool gat_train_dense(Plan &p, const int *rows, const int *plan, const int *plan_meta, int m, int nnz, int h,
+                            int f, bool v4) {
   if (!rows || !v4 || !dense_enabled()) return false;
   if (f != 8 && f != 16 && f != 32 && f != 64 && f != 128) return false;
-  if (!make_plan(p, plan, plan_meta, m, nnz, f)) return false;
+  if (!make_plan(p, plan, plan_meta, m, nnz, h, f)) return false;
   return p.num_dense > 0;
 }
 static bool plan_has_rest(const Plan &p) { return p.num_fit - p.num_dense + p.num_spill > 0; }
@@ -269,7 +280,7 @@ int dfgnn_gat_fwd_train(int m, int nnz, int h, int f, const int *row_ptr, const 
   const Csr g{m, nnz, h, f, row_ptr, col_ind, rows, nullptr};
   Plan p;
   const bool v4 = (f % 4 == 0) && aligned16(X) && aligned16(out);
-  if (gat_train_dense(p, rows, plan, plan_meta, m, nnz, f, v4)) {
+  if (gat_train_dense(p, rows, plan, plan_meta, m, nnz, h, f, v4)) {
     if (int rc = launch_gat_dense_fwd(g, p, attn_row, attn_col, negative_slope, X, out, as_stream(stream), edge_max,
                                       edge_sum, edge_mask, attn_drop))
       return rc;
@@ -296,7 +307,7 @@ int dfgnn_gat_bwd(int m, int nnz, int h, int f, const int *row_ptr, const int *c
   Plan p;
   const bool v4 = (f % 4 == 0) && aligned16(X) && aligned16(grad_out) && aligned16(grad_feat);
   const Plan *rest = nullptr;
-  if (gat_train_dense(p, rows, plan, plan_meta, m, nnz, f, v4)) {
+  if (gat_train_dense(p, rows, plan, plan_meta, m, nnz, h, f, v4)) {
     if (int rc = launch_gat_dense_bwd(g, p, attn_row, attn_col, negative_slope, X, edge_max, edge_sum, grad_out,
                                       grad_feat, grad_attn_row, grad_attn_col, as_stream(stream), edge_mask, attn_drop))
       return rc;

@@ -100,6 +100,8 @@ def lib():
         L.dfgnn_build_id.restype = ctypes.c_char_p
         L.dfgnn_plan_ints.argtypes = [ctypes.c_int, ctypes.c_int]
         L.dfgnn_plan_ints.restype = ctypes.c_size_t
+        L.dfgnn_plan_applies.argtypes = [ctypes.c_int] * 4 + [ctypes.c_void_p]
+        L.dfgnn_plan_applies.restype = ctypes.c_int
         L.dfgnn_preprocess_ws_bytes.argtypes = [ctypes.c_int, ctypes.c_int]
         L.dfgnn_preprocess_ws_bytes.restype = ctypes.c_size_t
         _lib = L

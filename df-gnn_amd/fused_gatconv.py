@@ -11,7 +11,7 @@ tensors from the training forward; its schedule argument only distributes work a
 import torch
 
 import dfgnn_native as _n
-from _binding_util import check_contiguous, check_device, check_dtype, get_plan, get_rows, ptr, stream_ptr
+from _binding_util import as_int32, check_contiguous, check_device, check_dtype, get_plan, get_rows, ptr, stream_ptr
 
 # Set to False to force the general (plan-less) kernels; results are identical either way.
 USE_BLOCK_PLAN = True
@@ -202,6 +202,7 @@ def gat_backward(negative_slope, attn_drop, row_ptr, col_ind, col_ptr, row_ind, 
     attn_drop = float(attn_drop)
     if not 0.0 <= attn_drop < 1.0:
         raise RuntimeError(f"attn_drop must be in [0, 1), got {attn_drop}")
+    permute = as_int32(permute)      # (dgl hands the CSC -> CSR permutation over as int64, like GT's val_idx)
     tensors = dict(col_ptr=col_ptr, row_ind=row_ind, permute=permute, edge_max=edge_max, edge_sum=edge_sum,
                    grad=grad)
     check_device(edge_mask=edge_mask, **tensors)

@@ -68,6 +68,11 @@ const char *dfgnn_build_id(void);
  * dfgnn_plan_build synchronises `stream` (it copies the 12 header words back); nothing else in this
  * library does. */
 size_t dfgnn_plan_ints(int m, int nnz);
+/* 1 if the entry points below would use a plan with this host header for (m, nnz, h, f), else 0 (they then take the
+ * general kernels, same results): the header must have been built for the same m, nnz, f; graphs with fewer than 8 edges
+ * per row on average and feature matrices of 4 GiB or more (m h f 4 >= 2^32: the plan kernels address a feature row
+ * with 32-bit byte offsets) do not use it.  Host-only, no GPU call. */
+int dfgnn_plan_applies(int m, int nnz, int h, int f, const int *plan_meta);
 int dfgnn_plan_build(int m, int nnz, int f, const int *row_ptr, const int *col_ind, int *plan,
                      int *meta_host, dfgnn_stream_t stream);
 

@@ -25,13 +25,39 @@ def test_header_symbols_exported():
 def test_loader_signatures_cover_header():
     import dfgnn_native
     compute = [n for n in _declared() if n not in ("dfgnn_abi_version", "dfgnn_error_string", "dfgnn_build_id",
-                                                       "dfgnn_plan_ints", "dfgnn_preprocess_ws_bytes")]
+                                                       "dfgnn_plan_ints", "dfgnn_plan_applies", "dfgnn_preprocess_ws_bytes")]
     assert sorted(dfgnn_native.SIGNATURES) == compute
     lib = dfgnn_native.lib()
     assert lib.dfgnn_abi_version() == 8
     assert b"bad argument" in lib.dfgnn_error_string(-1)
     assert b"unsupported" in lib.dfgnn_error_string(-2)
     assert lib.dfgnn_plan_ints(10, 40) >= 12 + 7 * 10 + 4 + 20  # header + lists + scratch (+ rocPRIM temporary storage) + edge coordinates
+
+
+def test_plan_fallback_predicate():
+    """dfgnn_plan_applies (host only): a plan is used only for the (m, nnz, f) it was built for, not for low-degree graphs,
+    and not for feature matrices of 4 GiB or more -- the plan kernels address feature rows with 32-bit byte offsets, the
+    general kernels they fall back to with size_t."""
+    import ctypes
+    import dfgnn_native
+    lib = dfgnn_native.lib()
+    budget = 160 * 1024 - 16 * 64 * 8 - 256      # kBlockLdsBudget (dfgnn_launch.hpp)
+
+    def applies(m, nnz, h, f, meta):
+        arr = (ctypes.c_int * 12)(*meta)
+        return lib.dfgnn_plan_applies(m, nnz, h, f, ctypes.addressof(arr))
+
+    m, nnz, f = 120000, 6000000, 128
+    meta = [1000, 0, 186, 15000, m, nnz, f, budget, 0, 1000, 300, 900000]
+    assert applies(m, nnz, 1, f, meta) == 1
+    assert applies(m, nnz, 8, f, meta) == 1                     # 0.49 GB of features
+    assert applies(m, nnz, 70, f, meta) == 0                    # 120000 x 70 x 128 x 4 B >= 4 GiB
+    assert applies(m + 1, nnz, 1, f, meta) == 0                 # another graph
+    assert applies(m, nnz, 1, 64, meta) == 0                    # another width
+    assert applies(m, nnz, 1, f, [0] + meta[1:]) == 0           # no fit range
+    low = [1000, 0, 186, 15000, m, 7 * m, f, budget, 0, 0, 0, 0]
+    assert applies(m, 7 * m, 1, f, low) == 0                    # fewer than 8 edges per row: the lane-group kernels
+    assert lib.dfgnn_plan_applies(m, nnz, 1, f, None) == 0
 
 
 def test_header_arity_matches_loader():
