@@ -306,16 +306,24 @@ def main():
         import fused_gatconv
         from _binding_util import build_plan
         from DFGNN.utils import GraphedStep
-        # (start the secondary figures from a clean allocator: with some step counts the cached blocks left by the timed loops
-        #  made every gat_forward output allocation miss the cache and doubled its time between events)
         del out, attn, gedge, dQ, dK, dV
         torch.cuda.empty_cache()
         with torch.no_grad():
+            # the GAT training pair through the C ABI with preallocated outputs, like the timed launches above (through the
+            # binding the per-call output allocations sometimes miss the allocator's cache and the events then bracket host
+            # time: 117 instead of 60 us)
             ar, ac, X = S.gat_features(m, h, f, seed=6, device=dev)
-            go, emax, esum, mask = fused_gatconv.gat_forward(ar, ac, W.row_ptr, W.col_ind, 0.2, X, 0.0)
-            gat_f = ev_us(lambda: fused_gatconv.gat_forward(ar, ac, W.row_ptr, W.col_ind, 0.2, X, 0.0))
-            gat_b = ev_us(lambda: fused_gatconv.gat_backward(0.2, 0.0, W.row_ptr, W.col_ind, W.col_ptr, W.row_ind, W.val_idx,
-                                                             emax, esum, mask, X, ar, ac, W.dO))
+            g_rows, g_plan, g_meta = fused_gatconv._train_plan(W.row_ptr, W.col_ind, f, 0.0)
+            go, gfeat = torch.empty_like(X), torch.empty_like(X)
+            emax, esum, g_ar, g_ac = (torch.empty(m, h, device=dev) for _ in range(4))
+            g_edge = torch.empty(h, nnz, device=dev)
+            gat_f = ev_us(checked(lambda: L.dfgnn_gat_fwd_train(m, nnz, h, f, P(W.row_ptr), P(W.col_ind), P(g_rows), P(ar), P(ac),
+                                                                0.2, P(X), None, 0.0, P(emax), P(esum), P(go), g_plan, g_meta,
+                                                                stream)))
+            gat_b = ev_us(checked(lambda: L.dfgnn_gat_bwd(m, nnz, h, f, P(W.row_ptr), P(W.col_ind), P(g_rows), P(W.col_ptr),
+                                                          P(W.row_ind), P(W.val_idx), P(ar), P(ac), 0.2, P(X), P(emax), P(esum),
+                                                          None, 0.0, P(W.dO), P(g_edge), P(gfeat), P(g_ar), P(g_ac), g_plan,
+                                                          g_meta, stream)))
         src, dst = W.g.edges()
 
         def raw_step():  # the launches of the timed step as explicit operator calls (no autograd bookkeeping)

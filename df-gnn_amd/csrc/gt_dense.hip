@@ -297,6 +297,11 @@ __device__ __forceinline__ void dense_fwd_body(float *lds, int lds_bytes, const 
       const LaneIds L = lane_ids();
       const int i = strip * 16 + L.mi;
       const unsigned char *mrow = map + i * MS + 4 * L.mq;
+      // One K chunk: the accumulators are the logits up to ONE positive factor (the two power-of-two scales), so the
+      // row maximum is taken on them as they are and the factor -- times log2 e -- goes into the exponent's FMA:
+      // p = 2^(S c2 - max c2).  Two chunks have a scale each: the logits are formed first.
+      constexpr bool kFold = NCH == 1;
+      const float c2 = (GAT ? 1.f : kinv[0] * qinv[s]) * 1.4426950408889634f;
       float mx = -INFINITY;
 #pragma unroll
       for (int jt = 0; jt < NT; ++jt) {
@@ -304,19 +309,21 @@ __device__ __forceinline__ void dense_fwd_body(float *lds, int lds_bytes, const 
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const bool edge = ((w >> (8 * r)) & 0xFFu) != 0xFFu;
-          const float x = edge ? (GAT ? S[s][jt][r] : S[s][jt][r] * (kinv[jt / TPC] * qinv[s])) : -INFINITY;
+          const float x = edge ? ((GAT || kFold) ? S[s][jt][r] : S[s][jt][r] * (kinv[jt / TPC] * qinv[s])) : -INFINITY;
           S[s][jt][r] = x;
           mx = fmaxf(mx, x);
         }
       }
       mx = xor16_32_max(mx);
+      if constexpr (kFold && !GAT) mx = (mx == -INFINITY) ? mx : mx * (kinv[0] * qinv[s]);  // the logit maximum itself
       const float base = (mx == -INFINITY) ? 0.f : mx;
       float sum = 0.f;
 #pragma unroll
       for (int jt = 0; jt < NT; ++jt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float p = fast_exp(S[s][jt][r] - base);  // exp(-inf) = 0 for the masked pairs
+          // exp(-inf) = 0 for the masked pairs
+          const float p = kFold ? __builtin_amdgcn_exp2f(fmaf(S[s][jt][r], c2, -base * 1.4426950408889634f)) : fast_exp(S[s][jt][r] - base);
           S[s][jt][r] = p;
           sum += p;
         }
