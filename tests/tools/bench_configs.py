@@ -157,9 +157,15 @@ if "c5" in args:
                 o, attn = _gtb.gt_hyper_forward(row_ptr_, rest[0], rows_, *rest[1:], Q, K, V)
                 return [o] + _gtb.gt_backward(row_ptr_, rest[0], rows_, *rest[1:], Q, K, V, attn, dO)
 
-        res, sec = benchmark(step)                           # (every eager run before the first capture: a captured
-        runs.append((heads, use_plan, f, m, nnz, step, raw_step, res, sec, row_ptr))  # graph keeps its memory pool)
-    for heads, use_plan, f, m, nnz, step, raw_step, res, sec, row_ptr in runs:
+        # (every eager run before the first capture: a captured graph keeps its memory pool.)  The reference's protocol
+        # (3 + 10 calls) five times over, median: one host hiccup inside a 10-call window -- an allocator miss, the
+        # collector -- otherwise shows up as a 5x .. 50x outlier of a ~100 us step (seen: 639, 1578 and 5739 us)
+        for _ in range(50):      # (the first ~30 steps of a process run at about half speed: clocks / allocator warm-up)
+            step()
+        trials = [benchmark(step) for _ in range(5)]
+        res, sec = trials[0][0], float(np.median([t[1] for t in trials]))
+        runs.append((heads, use_plan, f, m, nnz, step, raw_step, res, sec, row_ptr, [round(t[1] * 1e6, 1) for t in trials]))
+    for heads, use_plan, f, m, nnz, step, raw_step, res, sec, row_ptr, trials_us in runs:
         _gtb.USE_BLOCK_PLAN = use_plan
         graphed = GraphedStep(raw_step)                      # ... recorded once, replayed as one hipGraphLaunch
         res_g, sec_g = benchmark(graphed.replay)
@@ -175,7 +181,7 @@ if "c5" in args:
         byt = (16 * m * D + 12 * nnz + 4 * (m + 1) + 4 * heads * nnz) + (28 * m * D + 12 * heads * nnz + 16 * nnz + 8 * (m + 1))
         plan = getattr(row_ptr, "_dfgnn_plans", {}).get(f) if use_plan else None  # low-degree batches build none
         emit(config=f"C5 GT Peptides-like bs=256 dim=128 heads={heads} 'hyper' fwd+bwd plan={use_plan}", nodes=m, edges=nnz,
-             us=sec * 1e6, edges_per_s=nnz / sec, us_hipgraph=sec_g * 1e6, edges_per_s_hipgraph=nnz / sec_g,
+             us=sec * 1e6, us_trials=trials_us, edges_per_s=nnz / sec, us_hipgraph=sec_g * 1e6, edges_per_s_hipgraph=nnz / sec_g,
              max_abs_err=err, algorithmic_GBs=byt / sec / 1e9,
              hbm_frac=byt / sec / 1e9 / HBM, plan_fit=plan.num_fit if plan else 0,
              plan_spill=plan.num_spill if plan else 0)

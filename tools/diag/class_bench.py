@@ -30,7 +30,7 @@ for n in sizes:
         return float(np.median([a.elapsed_time(b) for a, b in evs])) * 1e3
     tf = ev(lambda: gt.gt_hyper_forward(*args))
     tb = ev(lambda: gt.gt_backward(*args, attn, dO))
-    fb = 16 * m * 128 + 12 * nnz + 4 * nnz      # bytes the forward has to move (Q K V out, rows col attn)
-    bb = 28 * m * 128 + 12 * nnz                 # backward: Q K V dO dQ dK dV, rows col attn
-    print(f"n={n:3d} (m={m}, nnz={nnz}): fwd {tf:6.1f} us = {tf*1e-6*2.0e9*256/bs/1e3:5.1f} kcyc/range@2GHz, {fb/tf/1e6:5.2f} TB/s | "
-          f"bwd {tb:6.1f} us = {tb*1e-6*2.0e9*256/bs/1e3:5.1f} kcyc/range, {bb/tb/1e6:5.2f} TB/s")
+    fb = 16 * m * 128 + 6 * nnz                  # bytes the forward moves: Q K V out, 2-byte edge coordinates, attn
+    bb = 28 * m * 128 + 6 * nnz                  # backward: Q K V dO dQ dK dV, coordinates, attn
+    print(f"n={n:3d} (m={m}, nnz={nnz}): fwd {tf:6.1f} us = {tf*1e-6*2.2e9*256/bs/1e3:5.1f} kcyc/range@2.2GHz, {fb/tf/1e6:5.2f} TB/s | "
+          f"bwd {tb:6.1f} us = {tb*1e-6*2.2e9*256/bs/1e3:5.1f} kcyc/range, {bb/tb/1e6:5.2f} TB/s")

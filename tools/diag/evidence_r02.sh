@@ -9,6 +9,7 @@ for h in 2 4 8; do timeout -k 10 200 python bench.py --heads $h --no-cpu-baselin
 timeout -k 10 300 python tests/tools/bench_configs.py c2 c5 c3gat > $O/configs.jsonl 2>&1
 timeout -k 10 300 python tools/train_stack.py > $O/train_stack.jsonl 2>&1
 timeout -k 10 200 python tools/diag/class_bench.py > $O/class_bench.txt 2>&1
+timeout -k 10 200 python tools/diag/wg_trace.py > $O/wg_trace.txt 2>&1
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_bench -o bench -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-c4 > $O/bench_profiled.json 2> $O/prof_bench.err
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_c4 -o c4 -- python3 $R/tools/run_kernel.py c4 5 > $O/prof_c4.log 2>&1
