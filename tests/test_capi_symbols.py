@@ -90,3 +90,10 @@ def test_torch_extension_binds_the_same_c_abi():
     assert set(used) <= set(_declared())
     ext = dfgnn_native.ext()
     assert ext is not None and ext.abi_version() == 8 and ext.build_id() == dfgnn_native.source_hash()
+
+
+def test_graft_entry_build_passes():
+    """__graft_entry__.build() -- what the driver runs on the CPU box every round: make is a no-op on an up-to-date tree,
+    the stale-library check, the ABI check against include/dfgnn.h and the package imports must all pass."""
+    import __graft_entry__ as g
+    g.build()
