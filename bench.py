@@ -273,7 +273,9 @@ def main():
     traffic = traffic_src = None
     try:
         prof = json.load(open(os.path.join(ROOT, PMC_PROFILE)))
-        if prof.get("m") == m and prof.get("nnz") == nnz and prof.get("h") == h and prof.get("f") == f:
+        import dfgnn_native
+        if (prof.get("m") == m and prof.get("nnz") == nnz and prof.get("h") == h and prof.get("f") == f and
+                prof.get("build_id") == dfgnn_native.build_id()):
             key = {"gt_hyper_fwd": "gt_dense_fwd_kernel", "gt_bwd": "gt_dense_bwd_kernel"}[dom]
             traffic = int(prof["traffic"][key]["total_bytes"])
             traffic_src = PMC_PROFILE + (" (library build %s)" % prof.get("build_id", "?"))
