@@ -34,6 +34,14 @@ __global__ __launch_bounds__(T) void probe(const float *__restrict__ buf, float 
         const float *p = base + (size_t)(r0 + row) * 128 + hh * 64 + 8 * c8;
         a[slot][k] = *reinterpret_cast<const float4 *>(p);
         b[slot][k] = *reinterpret_cast<const float4 *>(p + 4);
+      } else if (PATTERN == 2) {  // pattern 0 with non-temporal loads
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        const int C8 = FULLROW ? 16 : 8;
+        const int row = min(idx / C8, img_rows - 1), c8 = idx % C8;
+        const float *p = base + (size_t)(r0 + row) * 128 + hh * 64 + 8 * c8;
+        const f4 x = __builtin_nontemporal_load(reinterpret_cast<const f4 *>(p)), y = __builtin_nontemporal_load(reinterpret_cast<const f4 *>(p + 4));
+        a[slot][k] = make_float4(x[0], x[1], x[2], x[3]);
+        b[slot][k] = make_float4(y[0], y[1], y[2], y[3]);
       } else {
         // lane-contiguous: instruction k covers float4 chunks idx of the image; the second instruction the other half
         const int C4 = FULLROW ? 32 : 16;  // float4 chunks per row (half)
@@ -67,8 +75,12 @@ __global__ __launch_bounds__(T) void probe(const float *__restrict__ buf, float 
           for (int ft = 0; ft < 4; ++ft) {
             if (STORE == 1) {
               *reinterpret_cast<float4 *>(ob + (size_t)(strip * 16 + mi) * 128 + 16 * ft + 4 * mq) = v;
-            } else {  // the strip's 16 rows x 256 B as 4 x 1 KiB: instruction ft covers rows 4 ft .. 4 ft + 3 whole
+            } else if (STORE == 2) {  // the strip's 16 rows x 256 B as 4 x 1 KiB: instruction ft covers rows 4 ft .. 4 ft + 3 whole
               *reinterpret_cast<float4 *>(ob + (size_t)(strip * 16 + 4 * ft + (lane >> 4)) * 128 + 4 * (lane & 15)) = v;
+            } else {  // 3: the same shape, non-temporal stores
+              typedef float f4 __attribute__((ext_vector_type(4)));
+              const f4 w = {acc, acc, acc, acc};
+              __builtin_nontemporal_store(w, reinterpret_cast<f4 *>(ob + (size_t)(strip * 16 + 4 * ft + (lane >> 4)) * 128 + 4 * (lane & 15)));
             }
           }
         }
@@ -125,6 +137,10 @@ int main(int argc, char **argv) {
   run<0, 2, true, false, 2>("half rows, depth 2, + stores 4 rows x 256 B", buf, out, wgs, rows_per_wg, 160, obuf);
   run<0, 1, true, false, 1>("half rows, depth 1, + stores 16 rows x 64 B", buf, out, wgs, rows_per_wg, 160, obuf);
   run<0, 1, true, false, 2>("half rows, depth 1, + stores 4 rows x 256 B", buf, out, wgs, rows_per_wg, 160, obuf);
+  run<0, 1, true, false, 3>("half rows, depth 1, + NT stores 4 rows x 256 B", buf, out, wgs, rows_per_wg, 160, obuf);
+  run<2, 1, true, false, 0>("half rows, depth 1, NT loads", buf, out, wgs, rows_per_wg, 160, obuf);
+  run<2, 1, true, false, 3>("half rows, depth 1, NT loads + NT stores", buf, out, wgs, rows_per_wg, 160, obuf);
+  run<0, 1, true, false, 2>("half rows, depth 1, + stores 4 rows x 256 B (again)", buf, out, wgs, rows_per_wg, 160, obuf);
   run<0, 2, true, true>("full rows (80/img), 8-float pieces, depth 2", buf, out, wgs, rows_per_wg, 80);
   run<1, 2, true, true>("full rows (80/img), lane-contiguous, depth 2", buf, out, wgs, rows_per_wg, 80);
   run<1, 4, false, true>("full rows (80/img), lane-contiguous, depth 4, nb", buf, out, wgs, rows_per_wg, 80);
