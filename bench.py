@@ -295,7 +295,15 @@ def main():
             traffic_src = PMC_PROFILE + (" (library build %s)" % prof.get("build_id", "?"))
     except Exception:
         traffic = traffic_src = None
+    # the box's own device-to-device copy rate next to the datasheet peak (read + written bytes of a 1 GiB copy)
+    with torch.no_grad():
+        src_buf = torch.empty(1 << 28, dtype=torch.float32, device=dev)
+        dst_buf = torch.empty_like(src_buf)
+        copy_us = ev_us(lambda: dst_buf.copy_(src_buf), reps=5, warm=2)
+        copy_gbs = 2 * src_buf.numel() * 4 / (copy_us * 1e-6) / 1e9
+        del src_buf, dst_buf
     roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "measured_copy_GBs": round(copy_gbs, 1),
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "algorithmic_bytes": abytes[dom], "avg_us": round(kernel_us[dom], 2),
                 "all_kernels": {k: {"avg_us": round(v, 2), "algorithmic_bytes": abytes[k],
