@@ -248,10 +248,14 @@ def test_c5_peptides_like_full_size_against_oracle(oracle_mod, heads):
         _close(got, ref, f"C5 heads={heads} GAT training {what}")
 
 
-def test_c3_full_size_slices_against_oracle(oracle_mod):
+@pytest.mark.parametrize("heads", [1, 8])
+def test_c3_full_size_slices_against_oracle(oracle_mod, heads):
     """BASELINE.json configs[2] at its full size (bs = 1024, dim = 128, 'hyper' fwd + bwd on the matrix-core kernels):
     the batch is block-diagonal, so the oracle applied to a run of whole graphs equals that slice of the full result.
-    The first 128 and the last 128 graphs (a quarter of the batch) are checked: out, attn_edge, dQ, dK, dV."""
+    The first 128 and the last 128 graphs (a quarter of the batch) are checked: out, attn_edge, dQ, dK, dV.
+    heads = 8 (dim 128 as 8 heads of 16, `bench.py --heads 8`): the same batch through the multi-head bodies -- one
+    workgroup per graph takes the heads (dfgnn_dense_heads.hpp), the 1-D backward grid with per-head and walking
+    workgroups side by side."""
     import fused_gtconv as gt
     from DFGNN.layers import preprocess_Hyper_fw_bw
     from DFGNN.utils import synthetic as S
@@ -259,11 +263,12 @@ def test_c3_full_size_slices_against_oracle(oracle_mod):
     g = g_host.to(DEV)
     A, rows, row_ptr, col_ind, val, col_ptr, row_ind, val_idx, smem = preprocess_Hyper_fw_bw(g)
     m = g.num_nodes()
-    Q, K, V = S.gt_features(m, 1, 128, seed=100, device=DEV)
-    dO = torch.randn(m, 1, 128, generator=torch.Generator().manual_seed(7)).to(DEV)
+    f = 128 // heads
+    Q, K, V = S.gt_features(m, heads, f, seed=100, device=DEV)
+    dO = torch.randn(m, heads, f, generator=torch.Generator().manual_seed(7)).to(DEV)
     args = (row_ptr, col_ind, rows, val, col_ptr, row_ind, val_idx, smem, Q, K, V)
     out, attn = gt.gt_hyper_forward(*args)
-    plan = row_ptr._dfgnn_plans[128]
+    plan = row_ptr._dfgnn_plans[f]
     assert plan.num_dense == plan.num_fit > 1000 and plan.num_spill == 0
     dQ, dK, dV = gt.gt_backward(*args, attn, dO)
     sizes = g_host.batch_num_nodes().numpy()
@@ -279,10 +284,10 @@ def test_c3_full_size_slices_against_oracle(oracle_mod):
         q, k, v, do = (n_(t[n0:n1]) for t in (Q, K, V, dO))
         want, want_attn = oracle_mod.gt_forward(srp, sci, sv, q, k, v, want_attn=True)
         wq, wk, wv = oracle_mod.gt_backward(srp, sci, sv, q, k, v, do)
-        _close(out[n0:n1], want, f"C3 graphs {g0}:{g1} out")
-        _close(attn[:, e0:e1], want_attn, f"C3 graphs {g0}:{g1} attn_edge")
+        _close(out[n0:n1], want, f"C3 heads={heads} graphs {g0}:{g1} out")
+        _close(attn[:, e0:e1], want_attn, f"C3 heads={heads} graphs {g0}:{g1} attn_edge")
         for got, ref, what in ((dQ, wq, "dQ"), (dK, wk, "dK"), (dV, wv, "dV")):
-            _close(got[n0:n1], ref, f"C3 graphs {g0}:{g1} {what}")
+            _close(got[n0:n1], ref, f"C3 heads={heads} graphs {g0}:{g1} {what}")
 
 
 def test_c4_reddit_like_full_size_spot_rows():
