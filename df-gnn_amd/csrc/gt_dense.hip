@@ -1,7 +1,10 @@
 // gt_dense.hip -- matrix-core GT forward and backward for the dense ranges of a block plan.
 //
-// One workgroup of 8 waves per (dense range, head); wave w owns the 16-row strip w (and strip w + 8 of a range
-// with more than 128 nodes).  See dfgnn_dense.hpp for the numerics and the operand layouts.  These kernels replace,
+// One workgroup of 8 waves per dense range (single-head; multi-head: per range for the forward and for the backward of
+// ranges of <= 128 nodes, which walk the heads -- dfgnn_dense_heads.hpp -- else per (range, head)); wave w owns the
+// 16-row strip w (and strip w + 8 of a range with more than 128 nodes).  The sparse structure of a range arrives as
+// one uint16 per edge (row << 8 | column inside the range: the plan's `coords`, plan.hip).  See dfgnn_dense.hpp for the
+// numerics and the operand layouts.  These kernels replace,
 // for such ranges, the same reference kernels as gt_block.hip / gt_block_bwd.hip (fused_gtconv_hyper.cu:228-560,
 // fused_gtconv_backward.cu:40-191): the dot products, the softmax and the weighted sums of a whole member graph
 // are done as masked dense attention on v_mfma_f32_16x16x32_f16 (fp16 hi / lo operand halves under power-of-two
@@ -10,7 +13,8 @@
 // Forward:   S^T = K Q^T  ->  masked row softmax in registers  ->  O^T = V^T P^T
 //            The mask is a byte map [i][j] -> position of edge (i, j) in row i (0xFF: no edge), built once per
 //            range in LDS from the CSR arrays; it also tells where P_ij goes in attn_edge.
-// Backward:  P (attn_edge) is scattered into a dense fp32 tile; off-edge pairs have P = 0, hence dS = 0: no mask.
+// Backward:  P (attn_edge) is scattered into a dense tile (one-tile GT ranges: directly as fp16 hi | lo halves; else fp32,
+//            converted in place by the strips); off-edge pairs have P = 0, hence dS = 0: no mask.
 //            dV^T = dO^T P first (dO image resident; the strips take their dO rows -- the register operand of the next
 //            product -- from it, so dO is read from global memory once), then
 //            dP^T = V dO^T ;  t_i = sum_j P_ij dP_ij ;  dS = P o (dP - t)        (registers)
@@ -654,6 +658,15 @@ __device__ __forceinline__ void dense_bwd_body(float *lds, const Csr &g, int n0,
   // and, if `commit`, put the prefetched image into LDS.  The first PRE edges per thread of a range's first tile were
   // fetched in the prologue (pi, pj, pa) and are scattered ahead of the row-block loop (tile_open): used inside it they
   // would be live -- and spilled -- around the whole loop.
+  // One tile, GT: P goes into the tile as fp16 hi | lo halves (scale 2^14) straight from the scatter -- the form the column
+  // product wants -- and the strips read their rows back from it (hi + lo = P to 2^-24); no fp32 copy, no conversion
+  // pass, one barrier less.  (Two column blocks / GAT: P is scattered as fp32 and converted in place by its strips.)
+  constexpr bool kDirectP = !GAT && NBLK == 1;
+  auto put_p = [&](int i, int j, float p) {
+    const h16 hh = (h16)(p * kUnitScale);
+    Tb[i * TB + j] = hh;
+    Tb[i * TB + TS + j] = (h16)fmaf(p, kUnitScale, -(float)hh);
+  };
   auto tile_clear = [&]() {
     const int tid = opaque_tid();
     for (int k = tid; k < RBP * TS / 4; k += kDenseThreads)
@@ -668,6 +681,7 @@ __device__ __forceinline__ void dense_bwd_body(float *lds, const Csr &g, int n0,
       const int i = pc[k] >> 8, j = pc[k] & 0xFF;
       if (tid + k * kDenseThreads < eb - ea && j < CW) {
         if constexpr (GAT) T[i * TS + j] = gat_p(i, j, pa[k]);
+        else if constexpr (kDirectP) put_p(i, j, pa[k]);
         else T[i * TS + j] = pa[k];
       }
     }
@@ -691,6 +705,7 @@ __device__ __forceinline__ void dense_bwd_body(float *lds, const Csr &g, int n0,
         const int i = bc[k] >> 8, jj = bc[k] & 0xFF, j = jj - j0;
         if (base + tid + k * kDenseThreads < eb - ea && j >= 0 && j < CW) {
           if constexpr (GAT) T[(i - i0) * TS + j] = gat_p(i, jj, ba[k]);
+          else if constexpr (kDirectP) put_p(i - i0, j, ba[k]);
           else T[(i - i0) * TS + j] = ba[k];
         }
       }
@@ -841,8 +856,15 @@ __device__ __forceinline__ void dense_bwd_body(float *lds, const Csr &g, int n0,
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           if (16 * u < nj) {
-            const float4 p = *reinterpret_cast<const float4 *>(T + (wave * 16 + L.mi) * TS + 16 * u + 4 * L.mq);
-            Pr[jc][u] = f32x4{p.x, p.y, p.z, p.w};
+            if constexpr (kDirectP) {
+              const h16 *trow = Tb + (wave * 16 + L.mi) * TB + 16 * u + 4 * L.mq;
+              const hx4 h4 = *reinterpret_cast<const hx4 *>(trow), l4 = *reinterpret_cast<const hx4 *>(trow + TS);
+#pragma unroll
+              for (int r = 0; r < 4; ++r) Pr[jc][u][r] = ((float)h4[r] + (float)l4[r]) * kUnitScaleInv;
+            } else {
+              const float4 p = *reinterpret_cast<const float4 *>(T + (wave * 16 + L.mi) * TS + 16 * u + 4 * L.mq);
+              Pr[jc][u] = f32x4{p.x, p.y, p.z, p.w};
+            }
           } else {
             Pr[jc][u] = f32x4{0.f, 0.f, 0.f, 0.f};
           }
@@ -854,7 +876,7 @@ __device__ __forceinline__ void dense_bwd_body(float *lds, const Csr &g, int n0,
 #pragma unroll
             for (int r = 0; r < 4; ++r) Pd[u][r] = Pr[jc][u][r] > 0.f ? Pr[jc][u][r] : 0.f;  // (x drop.scale at the store)
           strip_to_tile(Pd, kUnitScale);
-        } else {
+        } else if constexpr (!kDirectP) {
           strip_to_tile(Pr[jc], kUnitScale);  // in place, own rows only; P lies in [0, 1]
         }
       } else {  // (defined on every path: otherwise the arrays are carried around the row-block loop in registers)
@@ -865,7 +887,7 @@ __device__ __forceinline__ void dense_bwd_body(float *lds, const Csr &g, int n0,
           for (int t = 0; t < KT; ++t) gh[t] = gl[t] = hx8{};
         }
       }
-      lds_barrier();
+      if constexpr (!kDirectP) lds_barrier();  // (the strips' in-place conversions)
       DFGNN_DSTAMP(3)
       column_phase(dVb, j0, ni, !first, doinv * kUnitScaleInv * (GAT ? ga.drop.scale : 1.f));
       if (jc + 1 == NBLK) image_post();  // V rows 0..
