@@ -59,7 +59,11 @@ def source_hash():
 
 
 def build_id(path=LIB_PATH):
-    """dfgnn_build_id() of a built library (plain ctypes: no torch, no GPU)."""
+    """dfgnn_build_id() of a built library (no GPU call).  torch is imported first, as in lib(): the HIP runtime that is
+    loaded first is the one the process uses, and a libdfgnn.so opened ahead of torch brings /opt/rocm's -- a later
+    operator call in the same process (build() followed by smoke()) then hands torch's device pointers to the other
+    runtime and fails with 'bad argument'."""
+    import torch  # noqa: F401
     L = ctypes.CDLL(path)
     L.dfgnn_build_id.restype = ctypes.c_char_p
     return L.dfgnn_build_id().decode()

@@ -2,6 +2,7 @@
 import ctypes
 import os
 import re
+import sys
 
 from conftest import ROOT
 
@@ -97,3 +98,14 @@ def test_graft_entry_build_passes():
     the stale-library check, the ABI check against include/dfgnn.h and the package imports must all pass."""
     import __graft_entry__ as g
     g.build()
+
+
+def test_nothing_opens_the_library_ahead_of_torch():
+    """The HIP runtime that is loaded first is the one a process uses: libdfgnn.so opened before `import torch` brings
+    /opt/rocm's, and operator calls later in that process then fail with 'bad argument' on torch's device pointers (seen:
+    build() followed by smoke() in one process on the GPU box).  Every loader path -- lib(), build_id(), ext() -- must have
+    torch in the process first."""
+    import subprocess
+    code = ("import sys; sys.path.insert(0, %r); import dfgnn_native as n; assert 'torch' not in sys.modules; "
+            "n.build_id(); assert 'torch' in sys.modules") % os.path.join(ROOT, "df-gnn_amd")
+    subprocess.run([sys.executable, "-c", code], check=True, timeout=300)
