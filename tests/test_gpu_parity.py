@@ -1360,6 +1360,49 @@ def test_multihead_forward_takes_heads_in_groups(oracle_mod, h, f):
         _close(got, ref, f"h={h} f={f} {what}")
 
 
+@pytest.mark.parametrize("heads", [1, 8])
+def test_dense_kernels_write_nothing_outside_their_outputs(heads):
+    """A poor man's sanitizer for the hand-written kernels (the pool has no GPU AddressSanitizer): every output of the
+    forward and the backward -- out, attn_edge, dQ, dK, dV -- lives in the middle of a larger buffer filled with a bit
+    pattern; after the launches (through the C ABI, as the bindings call it) the guard regions must be untouched and the
+    outputs fully written (no element still carries the pattern).  Mixed batch: <= 128, 129..160 and > 160 nodes, one
+    graph with more edges than the prefetch covers."""
+    import dfgnn_native
+    from _binding_util import get_plan
+    from DFGNN.layers import preprocess_Hyper_fw_bw
+    from DFGNN.utils import synthetic as S
+    L = dfgnn_native.lib()
+    g = _dense_batch([(100, 0.45), (128, 1.0), (129, 0.4), (150, 0.45), (160, 0.9), (161, 0.3), (200, 0.3), (33, 0.5)], seed=9)
+    A, rows, row_ptr, col_ind, val, col_ptr, row_ind, val_idx, smem = preprocess_Hyper_fw_bw(g)
+    m, nnz = g.num_nodes(), g.num_edges()
+    f = 128 // heads
+    Q, K, V = S.gt_features(m, heads, f, seed=3, device=DEV)
+    dO = torch.randn(m, heads, f, generator=torch.Generator().manual_seed(1)).to(DEV)
+    plan, meta, _ = get_plan(row_ptr, col_ind, f, True)
+    assert plan is not None and row_ptr._dfgnn_plans[f].num_dense == row_ptr._dfgnn_plans[f].num_fit
+    GUARD, PAT = 1 << 18, -1.2345678e30            # floats on either side; a value no kernel produces
+
+    def guarded(numel):
+        buf = torch.full((numel + 2 * GUARD,), PAT, device=DEV)
+        return buf, buf[GUARD:GUARD + numel]
+
+    bufs = {k: guarded(n) for k, n in (("out", m * heads * f), ("attn", heads * nnz), ("dQ", m * heads * f),
+                                        ("dK", m * heads * f), ("dV", m * heads * f), ("gedge", heads * nnz))}
+    P = lambda t: t.data_ptr()  # noqa: E731
+    stream = torch.cuda.current_stream().cuda_stream
+    assert L.dfgnn_gt_hyper_fwd(m, nnz, heads, f, P(row_ptr), P(col_ind), P(rows), None, P(Q), P(K), P(V),
+                                P(bufs["attn"][1]), None, P(bufs["out"][1]), plan, meta, stream) == 0
+    assert L.dfgnn_gt_bwd(m, nnz, heads, f, P(row_ptr), P(col_ind), P(rows), None, P(col_ptr), P(row_ind), P(val_idx), P(Q),
+                          P(K), P(V), P(bufs["attn"][1]), P(dO), P(bufs["gedge"][1]), P(bufs["dQ"][1]), P(bufs["dK"][1]),
+                          P(bufs["dV"][1]), plan, meta, stream) == 0
+    torch.cuda.synchronize()
+    for name, (buf, view) in bufs.items():
+        assert bool((buf[:GUARD] == PAT).all()) and bool((buf[-GUARD:] == PAT).all()), f"{name}: guard region written"
+        if name != "gedge":                        # (the dense path keeps dS on chip: grad_edge is left untouched)
+            assert not bool((view == PAT).any()), f"{name}: elements left unwritten"
+            assert bool(torch.isfinite(view).all()), name
+
+
 @pytest.mark.parametrize("seed", [0, 1, 2, 3, 4, 5])
 def test_multihead_random_batches(oracle_mod, seed):
     """Randomised multi-head batches through the walking workgroups (forward groups of heads, backward head walk): graph
