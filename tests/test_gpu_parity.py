@@ -1403,6 +1403,43 @@ def test_dense_kernels_write_nothing_outside_their_outputs(heads):
             assert bool(torch.isfinite(view).all()), name
 
 
+def test_gat_dense_kernels_write_nothing_outside_their_outputs():
+    """The same guard-region check for the GAT training pair on a dense batch (gat_dense_fwd / bwd kernels, 2 heads)."""
+    import dfgnn_native
+    import fused_gatconv
+    from DFGNN.layers import preprocess_Hyper_fw_bw
+    from DFGNN.utils import synthetic as S
+    L = dfgnn_native.lib()
+    g = _dense_batch([(100, 0.45), (128, 1.0), (129, 0.4), (160, 0.9), (161, 0.3), (200, 0.3), (33, 0.5)], seed=10)
+    A, rows, row_ptr, col_ind, val, col_ptr, row_ind, val_idx, smem = preprocess_Hyper_fw_bw(g)
+    m, nnz, h, f = g.num_nodes(), g.num_edges(), 2, 64
+    ar, ac, X = S.gat_features(m, h, f, seed=6, device=DEV)
+    dO = torch.randn(m, h, f, generator=torch.Generator().manual_seed(2)).to(DEV)
+    g_rows, plan, meta = fused_gatconv._train_plan(row_ptr, col_ind, f, 0.0)
+    assert plan is not None
+    GUARD, PAT = 1 << 18, -1.2345678e30
+
+    def guarded(numel):
+        buf = torch.full((numel + 2 * GUARD,), PAT, device=DEV)
+        return buf, buf[GUARD:GUARD + numel]
+
+    bufs = {k: guarded(n) for k, n in (("out", m * h * f), ("emax", m * h), ("esum", m * h), ("gfeat", m * h * f),
+                                        ("g_ar", m * h), ("g_ac", m * h), ("gedge", h * nnz))}
+    P = lambda t: t.data_ptr()  # noqa: E731
+    stream = torch.cuda.current_stream().cuda_stream
+    assert L.dfgnn_gat_fwd_train(m, nnz, h, f, P(row_ptr), P(col_ind), P(g_rows), P(ar), P(ac), 0.2, P(X), None, 0.0,
+                                 P(bufs["emax"][1]), P(bufs["esum"][1]), P(bufs["out"][1]), plan, meta, stream) == 0
+    assert L.dfgnn_gat_bwd(m, nnz, h, f, P(row_ptr), P(col_ind), P(g_rows), P(col_ptr), P(row_ind), P(val_idx), P(ar), P(ac),
+                           0.2, P(X), P(bufs["emax"][1]), P(bufs["esum"][1]), None, 0.0, P(dO), P(bufs["gedge"][1]),
+                           P(bufs["gfeat"][1]), P(bufs["g_ar"][1]), P(bufs["g_ac"][1]), plan, meta, stream) == 0
+    torch.cuda.synchronize()
+    for name, (buf, view) in bufs.items():
+        assert bool((buf[:GUARD] == PAT).all()) and bool((buf[-GUARD:] == PAT).all()), f"{name}: guard region written"
+        if name != "gedge":
+            assert not bool((view == PAT).any()), f"{name}: elements left unwritten"
+            assert bool(torch.isfinite(view).all()), name
+
+
 @pytest.mark.parametrize("seed", [0, 1, 2, 3, 4, 5])
 def test_multihead_random_batches(oracle_mod, seed):
     """Randomised multi-head batches through the walking workgroups (forward groups of heads, backward head walk): graph
