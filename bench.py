@@ -395,6 +395,22 @@ def main():
         cpu = {"value": e_s * n_rep / dt, "unit": "edges/s", "cores": oracle.num_threads(), "kind": "port",
                "sample": f"first {ng} graphs of the rank-0 batch ({n_s} nodes, {e_s} edges), fwd+bwd, "
                          f"{n_rep} reps in {dt:.1f}s, fp32 C/OpenMP oracle"}
+        # BASELINE.json configs[0] (the reference's own CPU-runnable case): GAT on the cora-like graph, f = 64, CSR -- the
+        # same CPU port, timed here because this leg is the one place of the bench that may run the oracle
+        from DFGNN.layers import preprocess_CSR
+        gc = S.cora_like()
+        c_rp, c_ci, _, _ = preprocess_CSR(gc)
+        c_ar, c_ac, c_x = S.gat_features(gc.num_nodes(), 1, 64, seed=4)
+        c_args = [t.numpy() for t in (c_rp, c_ci, c_ar, c_ac)] + [0.2, c_x.numpy()]
+        for _ in range(3):
+            oracle.gat_forward(*c_args, acc="f32")
+        t0 = time.perf_counter()
+        for _ in range(20):
+            oracle.gat_forward(*c_args, acc="f32")
+        c_dt = (time.perf_counter() - t0) / 20
+        cpu["c1_gat_cora_f64"] = {"workload": "GAT conv 'csr' on a cora-like graph, dim=64 (BASELINE.json configs[0]), CPU port",
+                                  "edges": gc.num_edges(), "ms": round(c_dt * 1e3, 4),
+                                  "edges_per_s": gc.num_edges() / c_dt, "cores": oracle.num_threads()}
 
     if rank == 0:
         line = {
