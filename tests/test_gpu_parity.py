@@ -5,11 +5,13 @@ Tolerance: BASELINE.json's north_star states "within 1e-3 fp32"; the reference's
 isclose(rtol=1e-3) (DFGNN/utils/util.py:211-214).  We assert  |got - want| <= ATOL + RTOL*|want|
 with ATOL = RTOL = 1e-3 on O(1)-scaled data, and in practice land near 1e-6.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
 
-from conftest import csc_of, random_graph
+from conftest import ROOT, csc_of, random_graph
 
 pytestmark = pytest.mark.gpu
 
@@ -1358,6 +1360,34 @@ def test_multihead_forward_takes_heads_in_groups(oracle_mod, h, f):
     wq, wk, wv = oracle_mod.gt_backward(n_(row_ptr), n_(col_ind), n_(val), n_(Q), n_(K), n_(V), n_(dO))
     for got, ref, what in ((dQ, wq, "dQ"), (dK, wk, "dK"), (dV, wv, "dV")):
         _close(got, ref, f"h={h} f={f} {what}")
+
+
+def test_bench_line_keeps_the_driver_contract():
+    """`python bench.py --steps K --warmup W` prints ONE JSON line with the keys the driver and the judge read: the metric,
+    whole-job value, the step time, `roofline` (bound / achieved / peak / unit / frac / traffic) and `cpu_baseline` (value /
+    unit / cores / kind / sample), `config.workload`, no model keys.  Run as a child process, as the driver runs it."""
+    import json
+    import subprocess
+    import sys
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "2", "--no-c4",
+                          "--cpu-sample-graphs", "8"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["unit"] == "edges/s" and d["n_gpus"] == 1 and d["steps"] == 5 and d["warmup"] == 2
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and 0.2 < r["frac"] < 1.0
+    assert "traffic" in r and (r["traffic"] is None or r["traffic"] > 1e8)
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["unit"] == "edges/s" and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
+    assert d["value"] == pytest.approx(d["config"]["total_edges"] / (d["ms_per_step"] * 1e-3), rel=1e-3)
 
 
 @pytest.mark.parametrize("heads", [1, 8])
