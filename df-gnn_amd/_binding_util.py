@@ -75,11 +75,25 @@ def val_ptr(val):
 # ---- block plan cache -----------------------------------------------------------------------------
 class BlockPlan:
     """Device plan buffer + its 12 host header words (include/dfgnn.h, dfgnn_plan_build)."""
-    __slots__ = ("buf", "meta", "_meta_c", "key")
+    __slots__ = ("buf", "meta", "_meta_c", "key", "_stats_ok")
 
     def __init__(self, buf, meta_c, key):
         self.buf, self._meta_c, self.key = buf, meta_c, key
         self.meta = list(meta_c)
+        self._stats_ok = {}
+
+    def stats_applies(self, h):
+        """dfgnn_gt_stats_applies for this plan and `h` heads (include/dfgnn.h): every range of the batch is served by
+        the matrix-core kernels, so the statistics-saving training pair can run it."""
+        ok = self._stats_ok.get(h)
+        if ok is None:
+            import ctypes
+
+            import dfgnn_native as _n
+            ok = bool(_n.lib().dfgnn_gt_stats_applies(self.meta[4], self.meta[5], h, self.meta[6],
+                                                      ctypes.addressof(self._meta_c)))
+            self._stats_ok[h] = ok
+        return ok
 
     @property
     def num_fit(self):
@@ -116,6 +130,13 @@ def build_plan(indptr, indices, f):
         _n.check(L.dfgnn_plan_build(m, nnz, f, indptr.data_ptr(), indices.data_ptr(), buf.data_ptr(),
                                     ctypes.addressof(meta), stream_ptr(indptr.device)), "dfgnn_plan_build")
     return BlockPlan(buf, meta, (indices.data_ptr(), nnz, indptr._version, indices._version, f))
+
+
+def get_plan_obj(indptr, indices, f, enable=True):
+    """The BlockPlan object behind get_plan (None when there is none)."""
+    if get_plan(indptr, indices, f, enable)[0] is None:
+        return None
+    return indptr.__dict__["_dfgnn_plans"][f]
 
 
 def get_plan(indptr, indices, f, enable=True):

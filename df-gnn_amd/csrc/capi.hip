@@ -3,7 +3,25 @@
 #include "../../include/dfgnn.h"
 #include "dfgnn_launch.hpp"
 
+#include <mutex>
+#include <set>
+#include <utility>
+
 using namespace dfgnn;
+
+namespace dfgnn {
+int set_max_lds_cached_ptr(const void *fn) {
+  static std::mutex mu;
+  static std::set<std::pair<int, const void *>> done;
+  int dev = 0;
+  if (hipError_t rc = hipGetDevice(&dev)) return (int)rc;
+  std::lock_guard<std::mutex> lock(mu);
+  if (done.count({dev, fn})) return 0;
+  if (hipError_t rc = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes)) return (int)rc;
+  done.insert({dev, fn});
+  return 0;
+}
+}  // namespace dfgnn
 
 namespace {
 inline hipStream_t as_stream(dfgnn_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
@@ -66,7 +84,8 @@ const char *dfgnn_error_string(int code) {
   if (code == 0) return "success";
   if (code == DFGNN_E_BADARG) return "dfgnn: bad argument (negative size or NULL required pointer)";
   if (code == DFGNN_E_UNSUPPORTED)
-    return "dfgnn: unsupported shape (f > 1024, f % 4 != 0 with f > 256, or h > 65535)";
+    return "dfgnn: unsupported shape (f > 1024, f % 4 != 0 with f > 256, or h > 65535) or, for the statistics-saving pair, a "
+           "batch that the matrix-core kernels do not cover (dfgnn_gt_stats_applies)";
   if (code > 0) return hipGetErrorString(static_cast<hipError_t>(code));
   return "dfgnn: unknown error";
 }
@@ -140,6 +159,47 @@ int dfgnn_gt_bwd(int m, int nnz, int h, int f, const int *row_ptr, const int *co
     return rc;
   return launch_gt_bwd_cols(g, col_ptr, row_ind, val_idx, Q, attn_edge, grad_edge, grad_out, dK, dV, chunks,
                             nchunks, as_stream(stream));
+}
+
+// ---- the statistics-saving training pair (gt_dense_stats.hip) -----------------------------------------------------------
+// usable when every range of the plan is served by the matrix-core kernels (unit edge values are the caller's promise)
+static bool gt_stats_plan(Plan &p, const int *plan, const int *plan_meta, int m, int nnz, int h, int f) {
+  if (!dense_enabled()) return false;
+  if (f != 8 && f != 16 && f != 32 && f != 64 && f != 128) return false;
+  if (!make_plan(p, plan, plan_meta, m, nnz, h, f)) return false;
+  return p.num_dense > 0 && p.num_dense == p.num_fit && p.num_spill == 0;
+}
+
+int dfgnn_gt_stats_applies(int m, int nnz, int h, int f, const int *plan_meta) {
+  Plan p;
+  static const int token = 0;
+  return gt_stats_plan(p, &token, plan_meta, m, nnz, h, f) ? 1 : 0;
+}
+
+int dfgnn_gt_hyper_fwd_stats(int m, int nnz, int h, int f, const int *row_ptr, const int *col_ind, const float *Q,
+                             const float *K, const float *V, float *row_max, float *row_sum, float *out,
+                             const int *plan, const int *plan_meta, dfgnn_stream_t stream) {
+  if (int c = check_common(m, nnz, h, f, row_ptr, col_ind)) return c < 0 ? c : 0;
+  if (!Q || !K || !V || !out || !row_max || !row_sum) return kErrBadArg;
+  Plan p;
+  if (!(aligned16(Q) && aligned16(K) && aligned16(V) && aligned16(out)) || !gt_stats_plan(p, plan, plan_meta, m, nnz, h, f))
+    return kErrUnsupported;
+  const Csr g{m, nnz, h, f, row_ptr, col_ind, nullptr, nullptr};
+  return launch_gt_dense_fwd_stats(g, p, Q, K, V, out, row_max, row_sum, as_stream(stream));
+}
+
+int dfgnn_gt_bwd_stats(int m, int nnz, int h, int f, const int *row_ptr, const int *col_ind, const float *Q,
+                       const float *K, const float *V, const float *row_max, const float *row_sum,
+                       const float *grad_out, float *dQ, float *dK, float *dV, const int *plan, const int *plan_meta,
+                       dfgnn_stream_t stream) {
+  if (int c = check_common(m, nnz, h, f, row_ptr, col_ind)) return c < 0 ? c : 0;
+  if (!Q || !K || !V || !row_max || !row_sum || !grad_out || !dQ || !dK || !dV) return kErrBadArg;
+  Plan p;
+  if (!(aligned16(Q) && aligned16(K) && aligned16(V) && aligned16(grad_out) && aligned16(dQ) && aligned16(dK) && aligned16(dV)) ||
+      !gt_stats_plan(p, plan, plan_meta, m, nnz, h, f))
+    return kErrUnsupported;
+  const Csr g{m, nnz, h, f, row_ptr, col_ind, nullptr, nullptr};
+  return launch_gt_dense_bwd_stats(g, p, Q, K, V, row_max, row_sum, grad_out, dQ, dK, dV, as_stream(stream));
 }
 
 int dfgnn_gt_tiling_fwd(int m, int nnz, int h, int f, const int *row_ptr, const int *col_ind, const float *val,

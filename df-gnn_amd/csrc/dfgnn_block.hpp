@@ -217,10 +217,11 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 size_t block_lds_bytes(const Plan &p, int f);
 
 // Raise a kernel's dynamic-LDS ceiling so launches above 64 KB are accepted.
+// (once per kernel and device: the launchers call this on every launch, the attribute call itself is remembered --
+// dfgnn_launch.hpp: set_max_lds_cached_ptr)
 template <class K>
-static int set_max_lds(K kernel) {
-  return (int)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  kLdsBytes);
+static int set_max_lds_cached(K kernel) {
+  return set_max_lds_cached_ptr(reinterpret_cast<const void *>(kernel));
 }
 
 }  // namespace dfgnn

@@ -16,6 +16,7 @@
 // gt_dense.hip's forward (fused_gtconv_hyper.cu:228-560, one launch covers all heads there too: blockIdx.y).
 #pragma once
 #include "dfgnn_dense.hpp"
+#include "dfgnn_dense_stamp.hpp"
 
 namespace dfgnn {
 
@@ -52,11 +53,15 @@ __device__ __forceinline__ void dense_kblock_mma_n(f32x4 (&acc)[NFT], f32x4 (&au
 }
 
 // FR: head width; NS strips per wave, NP padded rows (128 / 160); n <= NP, n > 8 * 16 * (NS - 1)
-template <int FR, bool WRITE_ATTN, int NS, int NP>
+// STATS: the forward of the statistics-saving training pair (see dense_fwd_body): edge bitmaps instead of the byte map,
+// row statistics (stat_max, stat_sum: [m, h]) instead of the attention values.
+template <int FR, bool WRITE_ATTN, int NS, int NP, bool STATS = false>
 __device__ __forceinline__ void dense_fwd_heads_body(float *lds, int lds_bytes, const Csr &g, int n0, int n, int e0, int ne,
                                                      const float *__restrict__ Q, const float *__restrict__ K,
                                                      const float *__restrict__ V, float *__restrict__ attn_edge,
-                                                     float *__restrict__ out) {
+                                                     float *__restrict__ out, float *__restrict__ stat_max = nullptr,
+                                                     float *__restrict__ stat_sum = nullptr) {
+  static_assert(!(STATS && WRITE_ATTN), "the statistics-saving forward writes no attention values");
   constexpr int FW = kHeadsGroupWidth, G = FW / FR, NT = NP / 16, KTH = FR == 64 ? 2 : 1, FTH = FR / 16;
   using D = DenseCfg<FW>;
   constexpr int RS = D::RS, KT = D::KT, FT = D::FT;
@@ -69,7 +74,7 @@ __device__ __forceinline__ void dense_fwd_heads_body(float *lds, int lds_bytes, 
   const int MS = npad + 4;
   h16 *khi = reinterpret_cast<h16 *>(lds), *klo = khi + (size_t)NP * RS, *vhi = klo + (size_t)NP * RS, *vlo = vhi + (size_t)NP * RS;
   unsigned char *map = reinterpret_cast<unsigned char *>(vlo + (size_t)NP * RS);
-  const int map_bytes = nstrip * 16 * MS;
+  const int map_bytes = STATS ? 0 : nstrip * 16 * MS;
   int *rp = reinterpret_cast<int *>(map + ((map_bytes + 15) & ~15));
   float *smax = reinterpret_cast<float *>(rp + ((n + 4) & ~3));  // [8] per-wave maxima of the K image, [8] of the V image
   float *stage0 = smax + 2 * kDenseWaves;
@@ -84,12 +89,12 @@ __device__ __forceinline__ void dense_fwd_heads_body(float *lds, int lds_bytes, 
   DFGNN_DSTAMP(0)
   // ---- prologue: every long-latency load goes out before the first barrier, the small ones first -----------------------
   int rp_mine = 0;
-  {
+  if constexpr (!STATS) {
     const int tid = opaque_tid();
     if (tid <= n) rp_mine = g.row_ptr[n0 + tid];
   }
   unsigned pre_c[kDensePre];
-  {
+  if constexpr (!STATS) {
     const int tid = opaque_tid();
 #pragma unroll
     for (int k = 0; k < kDensePre; ++k) {
@@ -114,13 +119,25 @@ __device__ __forceinline__ void dense_fwd_heads_body(float *lds, int lds_bytes, 
     }
   };
   q_fetch(Qb);
-  {
+  // STATS: the edge bitmaps of this lane's rows (plan.hip: masks), expanded below into the byte-map words the head loop
+  // tests (0x00 = edge, 0xFF = none), so that both forms share it
+  unsigned mbits[NS][STATS ? (NT + 1) / 2 : 1];
+  if constexpr (STATS) {
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const LaneIds L = lane_ids();
+      const unsigned *mp = g.mask + (size_t)(n0 + min((wave + 8 * s) * 16 + L.mi, n - 1)) * kPlanMaskWords;
+#pragma unroll
+      for (int w = 0; w < (NT + 1) / 2; ++w) mbits[s][w] = ld32(mp, (unsigned)w);
+    }
+  }
+  if constexpr (!STATS) {
     const int tid = opaque_tid();
     for (int k = tid; k < (map_bytes >> 2); k += kDenseThreads) reinterpret_cast<unsigned *>(map)[k] = 0xFFFFFFFFu;
     if (tid <= n) rp[tid] = rp_mine - e0;
+    lds_barrier();
   }
-  lds_barrier();
-  {  // byte map: position of every edge within its row (the plan guarantees distinct columns and rows < 255 long)
+  if constexpr (!STATS) {  // byte map: position of every edge within its row (the plan guarantees distinct columns and rows < 255 long)
     const int tid = opaque_tid();
 #pragma unroll
     for (int k = 0; k < kDensePre; ++k) {
@@ -163,11 +180,20 @@ __device__ __forceinline__ void dense_fwd_heads_body(float *lds, int lds_bytes, 
     const int strip = wave + 8 * s, i = strip * 16 + L.mi;
     const unsigned char *mrow = map + min(i, nstrip * 16 - 1) * MS + 4 * L.mq;
 #pragma unroll
-    for (int jt = 0; jt < NT; ++jt)
-      mw[s][jt] = (strip < nstrip && jt < ntile) ? *reinterpret_cast<const unsigned *>(mrow + 16 * jt) : 0xFFFFFFFFu;
-    row_e0[s] = rp[min(i, n)];
-    strip_e0[s] = rp[min(n, strip * 16)];
-    strip_e1[s] = rp[min(n, strip * 16 + 16)];
+    for (int jt = 0; jt < NT; ++jt) {
+      if constexpr (STATS) {
+        const unsigned b = (i < n && jt < ntile) ? (mbits[s][STATS ? jt / 2 : 0] >> (16 * (jt & 1) + 4 * L.mq)) & 0xFu : 0u;
+        // bit r -> byte r: 0x00 where the bit is set, 0xFF where it is not
+        mw[s][jt] = ~(((b & 1u) | ((b & 2u) << 7) | ((b & 4u) << 14) | ((b & 8u) << 21)) * 0xFFu);
+      } else {
+        mw[s][jt] = (strip < nstrip && jt < ntile) ? *reinterpret_cast<const unsigned *>(mrow + 16 * jt) : 0xFFFFFFFFu;
+      }
+    }
+    if constexpr (!STATS) {
+      row_e0[s] = rp[min(i, n)];
+      strip_e0[s] = rp[min(n, strip * 16)];
+      strip_e1[s] = rp[min(n, strip * 16 + 16)];
+    }
   }
 
   for (int gq = 0;; ++gq) {  // ---- one group of 64 feature columns (G heads) per trip --------------------------------
@@ -257,6 +283,13 @@ __device__ __forceinline__ void dense_fwd_heads_body(float *lds, int lds_bytes, 
             }
           sum = xor16_32_sum(sum);
           const float inv = (sum != 0.f) ? 1.f / sum : 0.f;
+          if constexpr (STATS) {
+            const int i = strip * 16 + L.mi;
+            if (i < n && L.mq == 0) {
+              stat_max[(size_t)(n0 + i) * g.h + head] = (mx == -INFINITY) ? -1e38f : mx * (ksc.inv * qinv);
+              stat_sum[(size_t)(n0 + i) * g.h + head] = sum;
+            }
+          }
           if (gq == 0 && q == 0 && s == 0) { DFGNN_DSTAMP(4) }
           if constexpr (WRITE_ATTN) {
             float *dst = attn_edge + (size_t)head * g.nnz + e0;

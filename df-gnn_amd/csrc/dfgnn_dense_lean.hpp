@@ -21,14 +21,19 @@ constexpr int kLeanThreads = 256;
 constexpr int kLeanWaves = kLeanThreads / kWave;
 constexpr int kLeanLdsBytes = 80 * 1024;
 
-template <int F, bool WRITE_ATTN>
+// STATS: the forward of the statistics-saving training pair (see dense_fwd_body): edge bitmaps instead of the byte map,
+// row statistics (stat_max, stat_sum: [m, h]) instead of the attention values.
+template <int F, bool WRITE_ATTN, bool STATS = false>
 __global__ __launch_bounds__(kLeanThreads, 2) void gt_dense_fwd_lean_kernel(Csr g, const int *__restrict__ fit,
                                                                            const float *__restrict__ Q,
                                                                            const float *__restrict__ K,
                                                                            const float *__restrict__ V,
                                                                            float *__restrict__ attn_edge,
-                                                                           float *__restrict__ out) {
+                                                                           float *__restrict__ out,
+                                                                           float *__restrict__ stat_max = nullptr,
+                                                                           float *__restrict__ stat_sum = nullptr) {
   static_assert(F == 64 || F == 128, "lean forward: whole 64-column halves only");
+  static_assert(!(STATS && WRITE_ATTN), "the statistics-saving forward writes no attention values");
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int FW = 64, NH = F / FW, NP = 128, NT = NP / 16, NS = 2, PRE = 16;
   using D = DenseCfg<FW>;
@@ -40,7 +45,7 @@ __global__ __launch_bounds__(kLeanThreads, 2) void gt_dense_fwd_lean_kernel(Csr 
   const int npad = (n + 31) & ~31, ntile = npad >> 4, nstrip = (n + 15) >> 4;
   h16 *ihi = reinterpret_cast<h16 *>(lds), *ilo = ihi + NP * RS;
   unsigned char *map = reinterpret_cast<unsigned char *>(ilo + NP * RS);
-  const int map_bytes = nstrip * 16 * MS;
+  const int map_bytes = STATS ? 0 : nstrip * 16 * MS;
   int *rp = reinterpret_cast<int *>(map + ((map_bytes + 15) & ~15));
   float *smax = reinterpret_cast<float *>(rp + ((n + 4) & ~3));  // [4] per-wave maxima of the image being staged
   float *pstage = smax + 4;                                       // [ne] normalised attention values, if it fits
@@ -121,12 +126,12 @@ __global__ __launch_bounds__(kLeanThreads, 2) void gt_dense_fwd_lean_kernel(Csr 
 
   // ---- prologue: everything that is needed first is requested first ------------------------------------------------
   int rp_mine = 0;
-  {
+  if constexpr (!STATS) {
     const int tid = opaque_tid();
     if (tid <= n) rp_mine = g.row_ptr[n0 + tid];
   }
   unsigned pre_c[PRE];  // packed (row, column) within the range (plan.hip: coords)
-  {
+  if constexpr (!STATS) {
     const int tid = opaque_tid();
 #pragma unroll
     for (int k = 0; k < PRE; ++k) {
@@ -136,13 +141,23 @@ __global__ __launch_bounds__(kLeanThreads, 2) void gt_dense_fwd_lean_kernel(Csr 
   }
   image_fetch(Kb);
   q_fetch(0);
-  {
+  unsigned mwords[NS][STATS ? NT / 2 : 1];  // STATS: the edge bitmaps of this lane's rows (plan.hip: masks)
+  if constexpr (STATS) {
+    const LaneIds L = lane_ids();
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const uint4 w = *reinterpret_cast<const uint4 *>(
+          g.mask + (size_t)(n0 + min((wave + kLeanWaves * s) * 16 + L.mi, n - 1)) * kPlanMaskWords);
+      mwords[s][0] = w.x; mwords[s][1] = w.y; mwords[s][2] = w.z; mwords[s][3] = w.w;
+    }
+  }
+  if constexpr (!STATS) {
     const int tid = opaque_tid();
     for (int k = tid; k < (map_bytes >> 2); k += kLeanThreads) reinterpret_cast<unsigned *>(map)[k] = 0xFFFFFFFFu;
     if (tid <= n) rp[tid] = rp_mine - e0;
+    lds_barrier();
   }
-  lds_barrier();
-  {  // byte map: position of every edge within its row (0xFF: no edge)
+  if constexpr (!STATS) {  // byte map: position of every edge within its row (0xFF: no edge)
     const int tid = opaque_tid();
 #pragma unroll
     for (int k = 0; k < PRE; ++k) {
@@ -221,10 +236,12 @@ __global__ __launch_bounds__(kLeanThreads, 2) void gt_dense_fwd_lean_kernel(Csr 
       float mx = -INFINITY;
 #pragma unroll
       for (int jt = 0; jt < NT; ++jt) {
-        const unsigned w = (jt < ntile) ? *reinterpret_cast<const unsigned *>(mrow + 16 * jt) : 0xFFFFFFFFu;
+        unsigned w = 0xFFFFFFFFu, wb = 0u;
+        if constexpr (STATS) wb = (i < n && jt < ntile) ? (mwords[s][STATS ? jt / 2 : 0] >> (16 * (jt & 1) + 4 * L.mq)) & 0xFu : 0u;
+        else w = (jt < ntile) ? *reinterpret_cast<const unsigned *>(mrow + 16 * jt) : 0xFFFFFFFFu;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const bool edge = ((w >> (8 * r)) & 0xFFu) != 0xFFu;
+          const bool edge = STATS ? ((wb >> r) & 1u) != 0u : ((w >> (8 * r)) & 0xFFu) != 0xFFu;
           const float x = edge ? S[s][jt][r] : -INFINITY;
           S[s][jt][r] = x;
           mx = fmaxf(mx, x);
@@ -243,6 +260,12 @@ __global__ __launch_bounds__(kLeanThreads, 2) void gt_dense_fwd_lean_kernel(Csr 
         }
       sum = xor16_32_sum(sum);
       inv[s] = (sum != 0.f) ? 1.f / sum : 0.f;
+      if constexpr (STATS) {
+        if (i < n && L.mq == 0) {
+          stat_max[(size_t)(n0 + i) * g.h + head] = (mx == -INFINITY) ? -1e38f : mx;
+          stat_sum[(size_t)(n0 + i) * g.h + head] = sum;
+        }
+      }
       if constexpr (WRITE_ATTN) {
         if (i < n) {
           float *lrow = pstage + rp[i];

@@ -18,6 +18,7 @@
 // to 2^-24); dS replaces it in place.  Numerics, layouts and helpers: dfgnn_dense.hpp.
 #pragma once
 #include "dfgnn_dense.hpp"
+#include "dfgnn_dense_stamp.hpp"
 
 namespace dfgnn {
 
@@ -30,19 +31,26 @@ extern __device__ unsigned long long *dfgnn_dense_stamps;
 #define DFGNN_WSTAMP(k)
 #endif
 
-template <int FR, int NP, int R, int FWMAX = 64>
+// RECOMP (backward of the statistics-saving pair, gt_dense_stats.hip): no attn_edge.  NH more image phases in front --
+// K.h -> S += Q.h K.h^T, the strips' Q rows straight from memory as register operands -- then P = 2^(S c - max c) / sum
+// on the edges of the plan's bitmap (g.mask) with the forward's row statistics (stat_max, stat_sum: [m, h]), written to
+// the tile by its strips (every row of the tile: nothing is cleared, nothing scattered).
+template <int FR, int NP, int R, int FWMAX = 64, bool RECOMP = false>
 __device__ __forceinline__ void dense_bwd_wide_body(float *lds, const Csr &g, int n0, int n, int e0, int ne, int head,
                                                     const float *__restrict__ Q, const float *__restrict__ K,
                                                     const float *__restrict__ V, const float *__restrict__ attn_edge,
                                                     const float *__restrict__ dO, float *__restrict__ dQ,
-                                                    float *__restrict__ dK, float *__restrict__ dV) {
+                                                    float *__restrict__ dK, float *__restrict__ dV,
+                                                    const float *__restrict__ stat_max = nullptr,
+                                                    const float *__restrict__ stat_sum = nullptr) {
   constexpr int F = FR < 32 ? 32 : FR;      // layout width (narrower heads run zero-padded, see dense_fwd_body)
   constexpr int FW = F < FWMAX ? F : FWMAX;  // image width: features staged at a time
   constexpr int NH = F / FW;                // feature halves
   using D = DenseCfg<FW>;
   constexpr int RS = D::RS, KT = D::KT, FT = D::FT;
   constexpr int U = NP / 16, TS = NP + 8, TB = 2 * TS, NS = (U + kDenseWaves - 1) / kDenseWaves, PRE = kDensePre;
-  constexpr int NQ = 4 * NH;  // images in all: dO.0 V.0 [dO.1 V.1] K.0 Q.0 [K.1 Q.1]
+  constexpr int QB = RECOMP ? NH : 0;  // images ahead of dO.0 (RECOMP: K.0 [K.1], for S)
+  constexpr int NQ = 4 * NH + QB;      // images in all: dO.0 V.0 [dO.1 V.1] K.0 Q.0 [K.1 Q.1]
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
   const int nstrip = (n + 15) >> 4;
   h16 *ihi = reinterpret_cast<h16 *>(lds), *ilo = ihi + (size_t)NP * RS;
@@ -53,7 +61,7 @@ __device__ __forceinline__ void dense_bwd_wide_body(float *lds, const Csr &g, in
   const float *Qb = Q + (size_t)n0 * hf + hoff, *Kb = K + (size_t)n0 * hf + hoff, *Vb = V + (size_t)n0 * hf + hoff,
               *dOb = dO + (size_t)n0 * hf + hoff;
   float *dQb = dQ + (size_t)n0 * hf + hoff, *dKb = dK + (size_t)n0 * hf + hoff, *dVb = dV + (size_t)n0 * hf + hoff;
-  const float *attn_h = attn_edge + (size_t)head * g.nnz + e0;
+  const float *attn_h = RECOMP ? nullptr : attn_edge + (size_t)head * g.nnz + e0;
   // real feature count of half h (padded widths: FR < 32 -> one half of FR features on the 32-wide layout)
   constexpr int fr = FR < FW ? FR : FW;
 
@@ -61,7 +69,7 @@ __device__ __forceinline__ void dense_bwd_wide_body(float *lds, const Csr &g, in
   // ---- prologue: edges and the first image are requested before anything else ------------------------------------
   unsigned pc[PRE];  // packed (row, column) within the range (plan.hip: coords)
   float pa[PRE];
-  {
+  if constexpr (!RECOMP) {
     const int tid = opaque_tid();
 #pragma unroll
     for (int k = 0; k < PRE; ++k) {
@@ -72,7 +80,9 @@ __device__ __forceinline__ void dense_bwd_wide_body(float *lds, const Csr &g, in
   }
   DenseStageRegs<FW, NP> st[R];  // image q travels in st[q % R]
   Pow2Scale isc{1.f, 1.f};
-  auto image_src = [&](int q) -> const float * {  // (q is a compile-time constant wherever this is called)
+  auto image_src = [&](int qq) -> const float * {  // (qq is a compile-time constant wherever this is called)
+    if (qq < QB) return Kb + qq * FW;
+    const int q = qq - QB;
     const int h = (q % (2 * NH)) / 2;
     const float *base = q < 2 * NH ? ((q & 1) ? Vb : dOb) : ((q & 1) ? Qb : Kb);
     return base + h * FW;
@@ -89,7 +99,107 @@ __device__ __forceinline__ void dense_bwd_wide_body(float *lds, const Csr &g, in
   };
 #pragma unroll
   for (int q = 0; q < R; ++q) image_fetch(q);
-  {  // tile := 0, then P of every edge as fp16 hi | lo (scale 2^14)
+  if constexpr (RECOMP) {
+    // ---- P recomputed: S = Q K^T over the feature halves, then the masked, normalised exponentials -> the tile ---------
+    float4 qa[NS][KT], qb[NS][KT];  // this lane's pieces of its strips' Q rows, one feature half, raw
+    auto q_fetch = [&](int h) {
+      const LaneIds L = lane_ids();
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        const unsigned off = (unsigned)min((wave + kDenseWaves * s) * 16 + L.mi, n - 1) * (unsigned)hf + (unsigned)(h * FW);
+#pragma unroll
+        for (int t = 0; t < KT; ++t) {
+          const unsigned c = (fr >= FW || 32 * t + 8 * L.mq < fr) ? 32u * t + 8u * L.mq : 0u;  // (past fr: zeroed below)
+          qa[s][t] = ld32_f4(Qb, off + c);
+          qb[s][t] = ld32_f4(Qb, off + c + 4);
+        }
+      }
+    };
+    hx8 qh[NS][KT], ql[NS][KT];
+    float qinv[NS];
+    auto q_convert = [&]() {
+      const LaneIds L = lane_ids();
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        const bool valid = (wave + kDenseWaves * s) * 16 + L.mi < n;
+        float qm = 0.f;
+#pragma unroll
+        for (int t = 0; t < KT; ++t) {
+          if (!valid || (fr < FW && 32 * t + 8 * L.mq >= fr)) qa[s][t] = qb[s][t] = make_float4(0.f, 0.f, 0.f, 0.f);
+          qm = fmaxf(qm, absmax8(qa[s][t], qb[s][t]));
+        }
+        const Pow2Scale qs = pow2_scale(wave_max(qm));
+        qinv[s] = qs.inv;
+#pragma unroll
+        for (int t = 0; t < KT; ++t) split_hx8(qa[s][t], qb[s][t], qs.s, qh[s][t], ql[s][t]);
+      }
+    };
+    q_fetch(0);
+    constexpr int MW = (U + 1) / 2;  // bitmap words of a row
+    unsigned mwd[NS][MW];
+    float smx[NS], sinv[NS];
+    {
+      const LaneIds L = lane_ids();
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        const int i = (wave + kDenseWaves * s) * 16 + L.mi;
+        const size_t node = (size_t)(n0 + min(i, n - 1));
+        const unsigned *mp = g.mask + node * kPlanMaskWords;
+#pragma unroll
+        for (int w = 0; w < MW; ++w) mwd[s][w] = (i < n) ? ld32(mp, (unsigned)w) : 0u;
+        smx[s] = stat_max[node * g.h + head];
+        const float ssum = stat_sum[node * g.h + head];
+        sinv[s] = (ssum != 0.f) ? 1.f / ssum : 0.f;
+      }
+    }
+    f32x4 S[NS][U];
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+      for (int u = 0; u < U; ++u) S[s][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+      image_post(h);
+      lds_barrier();  // (h > 0: the previous K half is free)
+      image_store(h);  // K, half h
+      q_convert();
+      if (h + 1 < NH) q_fetch(h + 1);
+      lds_barrier();
+      const LaneIds L = lane_ids();
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        if (wave + kDenseWaves * s < nstrip) {
+          const float c = isc.inv * qinv[s];
+#pragma unroll
+          for (int u = 0; u < U; ++u)
+            if (16 * u < n) S[s][u] += dense_rows_mma<FW>(ihi, ilo, u, qh[s], ql[s], L) * c;
+        }
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const int strip = wave + kDenseWaves * s;
+      if (strip < U) {  // every row of the tile is written: zeros past the range
+        const LaneIds L = lane_ids();
+        h16 *trow = Tb + (strip * 16 + L.mi) * TB + 4 * L.mq;
+        const float b = smx[s];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const unsigned bits = (mwd[s][u / 2] >> (16 * (u & 1) + 4 * L.mq)) & 0xFu;
+          hx4 h4, l4;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float p = ((bits >> r) & 1u) ? fast_exp(S[s][u][r] - b) * sinv[s] : 0.f;
+            const h16 hh = (h16)(p * kUnitScale);
+            h4[r] = hh;
+            l4[r] = (h16)fmaf(p, kUnitScale, -(float)hh);
+          }
+          *reinterpret_cast<hx4 *>(trow + 16 * u) = h4;
+          *reinterpret_cast<hx4 *>(trow + TS + 16 * u) = l4;
+        }
+      }
+    }
+  } else {  // tile := 0, then P of every edge as fp16 hi | lo (scale 2^14)
     const int tid = opaque_tid();
     for (int k = tid; k < NP * TS / 4; k += kDenseThreads) reinterpret_cast<float4 *>(T)[k] = make_float4(0.f, 0.f, 0.f, 0.f);
     lds_barrier();
@@ -117,9 +227,9 @@ __device__ __forceinline__ void dense_bwd_wide_body(float *lds, const Csr &g, in
         if (base + tid + k * kDenseThreads < ne) put(bc[k], ba[k]);
     }
   }
-  image_post(0);
+  image_post(QB);
   lds_barrier();
-  image_store(0);  // dO, half 0
+  image_store(QB);  // dO, half 0
   lds_barrier();
   DFGNN_WSTAMP(1)
 
@@ -194,10 +304,10 @@ __device__ __forceinline__ void dense_bwd_wide_body(float *lds, const Csr &g, in
     }
     column_phase(dVb + h * FW, doinv * kUnitScaleInv);
     if (h == 0) { DFGNN_WSTAMP(2) }
-    image_post(2 * h + 1);
+    image_post(QB + 2 * h + 1);
     lds_barrier();  // the dO image is free
     if (h == 0) { DFGNN_WSTAMP(12) }
-    image_store(2 * h + 1);  // V, half h
+    image_store(QB + 2 * h + 1);  // V, half h
     if (h == 0) { DFGNN_WSTAMP(14) }
     lds_barrier();
     if (h == 0) { DFGNN_WSTAMP(3) }
@@ -219,9 +329,9 @@ __device__ __forceinline__ void dense_bwd_wide_body(float *lds, const Csr &g, in
     }
     if (h == 0) { DFGNN_WSTAMP(4) }
     if (h + 1 < NH) {
-      image_post(2 * h + 2);
+      image_post(QB + 2 * h + 2);
       lds_barrier();  // the V image is free
-      image_store(2 * h + 2);  // dO, half h + 1
+      image_store(QB + 2 * h + 2);  // dO, half h + 1
       lds_barrier();
     }
   }
@@ -256,7 +366,7 @@ __device__ __forceinline__ void dense_bwd_wide_body(float *lds, const Csr &g, in
   }
   DFGNN_WSTAMP(6)
   wg_max_post(smax + kDenseWaves, tmax);
-  image_post(2 * NH);
+  image_post(QB + 2 * NH);
   lds_barrier();  // the V image and every strip's P rows are free
   const Pow2Scale ts = pow2_scale(wg_max_read(smax + kDenseWaves));
 #pragma unroll
@@ -279,7 +389,7 @@ __device__ __forceinline__ void dense_bwd_wide_body(float *lds, const Csr &g, in
       }
     }
   }
-  image_store(2 * NH);  // K, half 0
+  image_store(QB + 2 * NH);  // K, half 0
   lds_barrier();
   DFGNN_WSTAMP(7)
 
@@ -311,17 +421,17 @@ __device__ __forceinline__ void dense_bwd_wide_body(float *lds, const Csr &g, in
       }
     }
     if (h == 0) { DFGNN_WSTAMP(8) }
-    image_post(2 * NH + 2 * h + 1);
+    image_post(QB + 2 * NH + 2 * h + 1);
     lds_barrier();  // the K image is free
-    image_store(2 * NH + 2 * h + 1);  // Q, half h
+    image_store(QB + 2 * NH + 2 * h + 1);  // Q, half h
     lds_barrier();
     if (h == 0) { DFGNN_WSTAMP(9) }
     column_phase(dKb + h * FW, isc.inv * ts.inv);
     if (h == 0) { DFGNN_WSTAMP(10) }
     if (h + 1 < NH) {
-      image_post(2 * NH + 2 * h + 2);
+      image_post(QB + 2 * NH + 2 * h + 2);
       lds_barrier();  // the Q image is free
-      image_store(2 * NH + 2 * h + 2);  // K, half h + 1
+      image_store(QB + 2 * NH + 2 * h + 2);  // K, half h + 1
       lds_barrier();
     }
   }

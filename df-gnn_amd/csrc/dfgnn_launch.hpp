@@ -15,6 +15,10 @@ struct Csr {
   // matrix-core kernels only (set by their launchers from the plan): uint16 per edge, (row << 8 | column) within the
   // edge's dense range -- read instead of rows / col_ind
   const unsigned short *coords = nullptr;
+  // edge bitmaps of the dense ranges (plan.hip: masks), 8 words per node: bit c of mask[8 i ..] = node i has an edge to
+  // the node c places after the first node of its range; maskT likewise for the edges INTO node i.  Read by the
+  // statistics-saving training pair (gt_dense_stats.hip), which needs to know where the edges are but not their order.
+  const unsigned *mask = nullptr, *maskT = nullptr;
 };
 
 constexpr int kErrBadArg = -1;
@@ -44,6 +48,10 @@ constexpr int kPlanEdgeGlobal = 1 << 30;                 // flag on a fit range'
 constexpr int kPlanDense = 1 << 29;                      // flag on a fit range's n1: qualifies for the matrix-core kernels
 constexpr int kPlanRangeMask = ~(kPlanEdgeGlobal | kPlanDense);
 
+constexpr int kPlanMaskWords = 8;                        // 32-bit words of a node's edge bitmap (dense ranges: < 256 nodes)
+// int32 offset of the edge bitmaps in a plan buffer whose packed coordinates start at coords_off
+inline size_t plan_mask_off(size_t coords_off, int nnz) { return (coords_off + ((size_t)nnz + 1) / 2 + 4 + 3) & ~(size_t)3; }
+
 struct Plan {              // host view of a built plan (see plan.hip for the device layout)
   const int *dev;          // device buffer, may be null (= no plan: general kernels only)
   int num_fit, num_spill, max_fit_nodes, max_fit_edges, m, nnz, f, num_edge_global;
@@ -51,6 +59,10 @@ struct Plan {              // host view of a built plan (see plan.hip for the de
   int num_dense_wide = 0;  // ... and the first num_dense_wide of those have more than 128 nodes
   int coords_off = 0;      // int32 offset of the packed edge coordinates of the dense ranges (plan.hip)
   const unsigned short *coords() const { return reinterpret_cast<const unsigned short *>(dev + coords_off); }
+  // the edge bitmaps behind the coordinates: mask[8 m], maskT[8 m] (see Csr)
+  size_t mask_off() const { return plan_mask_off((size_t)coords_off, nnz); }
+  const unsigned *mask() const { return reinterpret_cast<const unsigned *>(dev + mask_off()); }
+  const unsigned *maskT() const { return mask() + 8 * (size_t)m; }
   const int *fit() const { return dev + kPlanHeader; }
   const int *spill() const { return dev + kPlanHeader + 2 * (size_t)m; }
 };
@@ -86,6 +98,8 @@ int dispatch_cfg(int f, bool vec4, F &&fn) {
 }
 
 inline int launch_status() { return static_cast<int>(hipGetLastError()); }
+// hipFuncSetAttribute(fn, MaxDynamicSharedMemorySize, 160 KB), issued once per (device, kernel) and remembered (capi.hip)
+int set_max_lds_cached_ptr(const void *fn);
 
 // ---- launchers implemented in the kernel translation units -----------------------------------
 int launch_gt_hyper_fwd(const Csr &g, const float *Q, const float *K, const float *V, float *attn_edge,
@@ -101,6 +115,12 @@ int launch_gt_dense_fwd(const Csr &g, const Plan &p, const float *Q, const float
 int launch_gt_dense_bwd(const Csr &g, const Plan &p, const float *Q, const float *K, const float *V,
                         const float *attn_edge, const float *grad_out, float *dQ, float *dK, float *dV,
                         hipStream_t s);
+// the statistics-saving training pair (gt_dense_stats.hip): no attn_edge, row statistics [m, h] instead
+int launch_gt_dense_fwd_stats(const Csr &g, const Plan &p, const float *Q, const float *K, const float *V, float *out,
+                              float *stat_max, float *stat_sum, hipStream_t s);
+int launch_gt_dense_bwd_stats(const Csr &g, const Plan &p, const float *Q, const float *K, const float *V,
+                              const float *stat_max, const float *stat_sum, const float *grad_out, float *dQ, float *dK,
+                              float *dV, hipStream_t s);
 // edge_max / edge_sum (nullable): row statistics for the GAT training pair
 int launch_gat_dense_fwd(const Csr &g, const Plan &p, const float *attn_row, const float *attn_col, float slope,
                          const float *X, float *out, hipStream_t s, float *edge_max = nullptr,

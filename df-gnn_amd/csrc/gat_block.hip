@@ -99,7 +99,7 @@ int launch_gat_block_fwd(const Csr &g, const Plan &p, const float *attn_row, con
   const size_t lds = block_lds_bytes(p, g.f);
   return dispatch_vec4(g.f, [&](auto cfg) {
     using C = decltype(cfg);
-    if (int rc = set_max_lds(gat_block_fwd_kernel<C>)) return rc;
+    if (int rc = set_max_lds_cached(gat_block_fwd_kernel<C>)) return rc;
     gat_block_fwd_kernel<C><<<grid, kBlockThreads, lds, s>>>(g, fit, attn_row, attn_col, slope, X, edge_ws, out);
     return launch_status();
   });

@@ -174,11 +174,11 @@ int launch_gt_block_fwd(const Csr &g, const Plan &p, const float *Q, const float
   return dispatch_vec4(g.f, [&](auto cfg) {
     using C = decltype(cfg);
     if (attn_edge) {
-      if (int rc = set_max_lds(gt_block_fwd_kernel<C, true>)) return rc;
+      if (int rc = set_max_lds_cached(gt_block_fwd_kernel<C, true>)) return rc;
       gt_block_fwd_kernel<C, true><<<grid, kBlockThreads, lds, s>>>(g, fit, Q, K, V, attn_edge, edge_ws, out,
                                                                      (int)lds);
     } else {
-      if (int rc = set_max_lds(gt_block_fwd_kernel<C, false>)) return rc;
+      if (int rc = set_max_lds_cached(gt_block_fwd_kernel<C, false>)) return rc;
       gt_block_fwd_kernel<C, false><<<grid, kBlockThreads, lds, s>>>(g, fit, Q, K, V, nullptr, edge_ws, out,
                                                                       (int)lds);
     }

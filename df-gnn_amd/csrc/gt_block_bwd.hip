@@ -258,7 +258,7 @@ int launch_gt_block_bwd(const Csr &g, const Plan &p, const int *col_ptr, const i
   const int *fit = p.fit() + 2 * (size_t)first;
   return dispatch_vec4(g.f, [&](auto cfg) {
     using C = decltype(cfg);
-    if (int rc = set_max_lds(gt_block_bwd_kernel<C>)) return rc;
+    if (int rc = set_max_lds_cached(gt_block_bwd_kernel<C>)) return rc;
     gt_block_bwd_kernel<C><<<grid, kBlockThreads, kLdsBytes, s>>>(g, fit, col_ptr, row_ind, val_idx, Q, K, V,
                                                                   attn_edge, grad_out, edge_ws, dQ, dK, dV);
     return launch_status();

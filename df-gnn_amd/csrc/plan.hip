@@ -18,6 +18,8 @@
 //                                    largest first
 //   [12+2m .. 12+4m)    spill chunks (r0, r1) pairs, r1 - r0 <= kHyperRows
 //   [12+4m .. )         scratch: pairs[m] (cover, bad) as int2, bounds[m+1], count, rocPRIM temporary storage
+//   [.. behind coords)  mask[8 m], maskT[8 m]: edge bitmaps of the dense ranges, 8 words per node (plan_coords_kernel;
+//                       offset: dfgnn_launch.hpp:plan_mask_off) -- for the kernels that need the edge SET only
 //   [hdr[11] .. )       coords: uint16[nnz], for every edge e of a dense range (i - n0) << 8 | (j - n0) -- its row and
 //                       column within the range (both < 256).  The matrix-core kernels read these 2 bytes per edge
 //                       instead of rows[e] and col_ind[e] (8 bytes): the sparse structure of a dense range costs a
@@ -377,21 +379,37 @@ __global__ __launch_bounds__(kPlanThreads) void plan_cut_kernel(int m, int nnz, 
   }
 }
 
-// coords[e] of every edge of the dense ranges (the first hdr[9] fit ranges).  Runs after plan_cut_kernel on the same
-// stream; the range count is read on the device, so no host round trip.
+// coords[e] of every edge of the dense ranges (the first hdr[9] fit ranges) and the ranges' edge bitmaps: bit c of
+// mask[8 i ..] <=> edge (i, n0 + c), bit r of maskT[8 j ..] <=> edge (n0 + r, j) (LDS atomics, then whole rows out).
+// Runs after plan_cut_kernel on the same stream; the range count is read on the device, so no host round trip.
 __global__ __launch_bounds__(256) void plan_coords_kernel(const int *__restrict__ row_ptr,
                                                           const int *__restrict__ col_ind, const int *plan,
-                                                          unsigned short *__restrict__ coords) {
+                                                          unsigned short *__restrict__ coords,
+                                                          unsigned *__restrict__ mask, unsigned *__restrict__ maskT) {
+  __shared__ unsigned s_mask[2][256 * kPlanMaskWords];
   const int ndense = plan[9];
   const int *fit = plan + kPlanHeader;
   const int grp = threadIdx.x / kExtentLanes, gl = threadIdx.x % kExtentLanes;
   for (int k = blockIdx.x; k < ndense; k += gridDim.x) {
     const int n0 = fit[2 * k], n1 = fit[2 * k + 1] & kPlanRangeMask;
+    const int words = (n1 - n0) * kPlanMaskWords;
+    for (int t = threadIdx.x; t < words; t += 256) s_mask[0][t] = s_mask[1][t] = 0u;
+    __syncthreads();
     for (int i = n0 + grp; i < n1; i += 256 / kExtentLanes) {
       const int ea = row_ptr[i], eb = row_ptr[i + 1];
-      for (int e = ea + gl; e < eb; e += kExtentLanes)
-        coords[e] = (unsigned short)(((i - n0) << 8) | ((col_ind[e] - n0) & 0xFF));
+      for (int e = ea + gl; e < eb; e += kExtentLanes) {
+        const int r = i - n0, c = (col_ind[e] - n0) & 0xFF;
+        coords[e] = (unsigned short)((r << 8) | c);
+        atomicOr(&s_mask[0][r * kPlanMaskWords + (c >> 5)], 1u << (c & 31));
+        atomicOr(&s_mask[1][c * kPlanMaskWords + (r >> 5)], 1u << (r & 31));
+      }
     }
+    __syncthreads();
+    for (int t = threadIdx.x; t < words; t += 256) {
+      mask[(size_t)n0 * kPlanMaskWords + t] = s_mask[0][t];
+      maskT[(size_t)n0 * kPlanMaskWords + t] = s_mask[1][t];
+    }
+    __syncthreads();
   }
 }
 
@@ -419,7 +437,7 @@ static size_t plan_coords_off(int m) {
 }
 size_t dfgnn_plan_ints(int m, int nnz) {
   if (m < 0 || nnz < 0) return 0;
-  return plan_coords_off(m) + ((size_t)nnz + 1) / 2 + 4;
+  return plan_mask_off(plan_coords_off(m), nnz) + 2 * (size_t)kPlanMaskWords * (size_t)m + 4;
 }
 
 int dfgnn_plan_build(int m, int nnz, int f, const int *row_ptr, const int *col_ind, int *plan, int *meta_host,
@@ -459,8 +477,10 @@ int dfgnn_plan_build(int m, int nnz, int f, const int *row_ptr, const int *col_i
                                                    count, (int)coords_off);
   if (int rc = launch_status()) return rc;
   if (nnz > 0) {
+    unsigned *mask = reinterpret_cast<unsigned *>(plan + plan_mask_off(coords_off, nnz));
     plan_coords_kernel<<<(unsigned)min(m, 2048), 256, 0, s>>>(row_ptr, col_ind, plan,
-                                                             reinterpret_cast<unsigned short *>(plan + coords_off));
+                                                             reinterpret_cast<unsigned short *>(plan + coords_off), mask,
+                                                             mask + (size_t)kPlanMaskWords * m);
     if (int rc = launch_status()) return rc;
   }
   if (hipError_t rc = hipMemcpyAsync(meta_host, plan, kPlanHeader * sizeof(int), hipMemcpyDeviceToHost, s)) return (int)rc;

@@ -122,6 +122,58 @@ std::vector<Tensor> gt_bwd(const Tensor &row_ptr, const Tensor &col_ind, const T
   return {dQ, dK, dV};
 }
 
+// ---- the statistics-saving training pair (include/dfgnn.h: dfgnn_gt_hyper_fwd_stats / dfgnn_gt_bwd_stats) ---------------
+GtDims gt_stats_checks(const Tensor &row_ptr, const Tensor &col_ind, const Tensor &Q, const Tensor &K, const Tensor &V) {
+  check_i32(row_ptr, "row_ptr");
+  check_i32(col_ind, "col_ind");
+  check_feat3(Q, Q, "Q");
+  check_feat3(K, Q, "K");
+  check_feat3(V, Q, "V");
+  TORCH_CHECK(row_ptr.dim() == 1 && col_ind.dim() == 1, "indptr / indices must be 1-D");
+  TORCH_CHECK(row_ptr.size(0) - 1 == Q.size(0), "indptr describes ", row_ptr.size(0) - 1, " rows but features have ", Q.size(0),
+              " nodes");
+  for (const Tensor *t : {&row_ptr, &col_ind, &K, &V})
+    TORCH_CHECK(t->device() == Q.device(), "every tensor must live on the device of Q (", Q.device(), "), got ", t->device());
+  return GtDims{(int)Q.size(0), (int)col_ind.size(0), (int)Q.size(1), (int)Q.size(2)};
+}
+
+std::vector<Tensor> gt_hyper_fwd_stats(const Tensor &row_ptr, const Tensor &col_ind, const Tensor &Q, const Tensor &K,
+                                       const Tensor &V, int64_t plan, int64_t meta) {
+  const GtDims d = gt_stats_checks(row_ptr, col_ind, Q, K, V);
+  c10::hip::HIPGuardMasqueradingAsCUDA guard(Q.device());
+  Tensor out = torch::empty_like(Q);
+  Tensor row_max = torch::empty({d.m, d.h}, Q.options()), row_sum = torch::empty({d.m, d.h}, Q.options());
+  check_rc(dfgnn_gt_hyper_fwd_stats(d.m, d.nnz, d.h, d.f, row_ptr.data_ptr<int>(), col_ind.data_ptr<int>(), Q.data_ptr<float>(),
+                                    K.data_ptr<float>(), V.data_ptr<float>(), row_max.data_ptr<float>(),
+                                    row_sum.data_ptr<float>(), out.data_ptr<float>(), plan_ptr(plan), plan_ptr(meta),
+                                    cur_stream()),
+           "gt_hyper_forward_stats");
+  return {out, row_max, row_sum};
+}
+
+std::vector<Tensor> gt_bwd_stats(const Tensor &row_ptr, const Tensor &col_ind, const Tensor &Q, const Tensor &K,
+                                 const Tensor &V, const Tensor &row_max, const Tensor &row_sum, const Tensor &grad,
+                                 int64_t plan, int64_t meta) {
+  const GtDims d = gt_stats_checks(row_ptr, col_ind, Q, K, V);
+  check_feat3(grad, Q, "grad");
+  check_f32(row_max, "row_max");
+  check_f32(row_sum, "row_sum");
+  for (const Tensor *t : {&row_max, &row_sum}) {
+    TORCH_CHECK(t->dim() == 2 && t->size(0) == d.m && t->size(1) == d.h, "row_max / row_sum must have shape (", d.m, ", ", d.h,
+                "), got ", t->sizes());
+    TORCH_CHECK(t->device() == Q.device(), "row statistics must live on the device of Q");
+  }
+  TORCH_CHECK(grad.device() == Q.device(), "grad must live on the device of Q");
+  c10::hip::HIPGuardMasqueradingAsCUDA guard(Q.device());
+  Tensor dQ = torch::empty_like(Q), dK = torch::empty_like(K), dV = torch::empty_like(V);
+  check_rc(dfgnn_gt_bwd_stats(d.m, d.nnz, d.h, d.f, row_ptr.data_ptr<int>(), col_ind.data_ptr<int>(), Q.data_ptr<float>(),
+                              K.data_ptr<float>(), V.data_ptr<float>(), row_max.data_ptr<float>(), row_sum.data_ptr<float>(),
+                              grad.data_ptr<float>(), dQ.data_ptr<float>(), dK.data_ptr<float>(), dV.data_ptr<float>(),
+                              plan_ptr(plan), plan_ptr(meta), cur_stream()),
+           "gt_backward_stats");
+  return {dQ, dK, dV};
+}
+
 struct GatDims {
   int m, nnz, h, f;
 };
@@ -197,6 +249,8 @@ PYBIND11_MODULE(_dfgnn_ext, m) {
   m.def("build_id", [] { return std::string(dfgnn_build_id()); });
   m.def("gt_hyper_fwd", &gt_hyper_fwd, "fused GT conv 'hyper' forward (inference / training)");
   m.def("gt_bwd", &gt_bwd, "fused GT conv backward");
+  m.def("gt_hyper_fwd_stats", &gt_hyper_fwd_stats, "fused GT conv 'hyper' training forward, row statistics instead of attn_edge");
+  m.def("gt_bwd_stats", &gt_bwd_stats, "fused GT conv backward from the row statistics");
   m.def("gat_hyper_fwd", &gat_hyper_fwd, "fused GAT conv 'hyper' inference");
   m.def("gat_softmax_fwd", &gat_softmax_fwd, "fused GAT conv 'softmax' / 'softmax_gm' inference");
   m.def("gat_tiling_fwd", &gat_tiling_fwd, "fused GAT conv 'tiling' inference");

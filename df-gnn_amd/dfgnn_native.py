@@ -20,6 +20,9 @@ SIGNATURES = {
     "dfgnn_preprocess_hyper": [_i, _i, _vp, _vp, _i] + [_vp] * 8 + [ctypes.c_size_t, _vp],
     "dfgnn_gt_hyper_fwd": [_i, _i, _i, _i] + [_vp] * 13,
     "dfgnn_gt_bwd": [_i, _i, _i, _i] + [_vp] * 19,
+    "dfgnn_gt_stats_applies": [_i, _i, _i, _i, _vp],
+    "dfgnn_gt_hyper_fwd_stats": [_i, _i, _i, _i] + [_vp] * 11,
+    "dfgnn_gt_bwd_stats": [_i, _i, _i, _i] + [_vp] * 14,
     "dfgnn_gt_bwd_rows": [_i, _i, _i, _i] + [_vp] * 11,
     "dfgnn_gt_bwd_cols": [_i, _i, _i, _i] + [_vp] * 11,
     "dfgnn_gt_tiling_fwd": [_i, _i, _i, _i] + [_vp] * 8,

@@ -13,7 +13,9 @@ type (RuntimeError) as the reference.  Differences, all deliberate (SURVEY.md 8b
 import torch
 
 import dfgnn_native as _n
-from _binding_util import (as_int32, check_contiguous, check_device, check_dtype, check_feat3, get_plan, ptr,
+import os
+
+from _binding_util import (as_int32, check_contiguous, check_device, check_dtype, check_feat3, get_plan, get_plan_obj, ptr,
                            stream_ptr, val_ptr)
 
 # Set to False to force the general (plan-less) kernels; results are identical either way.
@@ -131,6 +133,69 @@ def gt_backward(row_ptr, col_ind, rows, val, col_ptr, row_ind, val_idx, smem_con
                                        ptr(col_ptr), ptr(row_ind), ptr(val_idx), ptr(Q), ptr(K), ptr(V),
                                        ptr(attn_edge), ptr(grad), ptr(grad_edge), ptr(dQ), ptr(dK), ptr(dV),
                                        plan, meta, stream_ptr(Q.device)), "gt_backward")
+    return [dQ, dK, dV]
+
+
+# ---- the statistics-saving training pair (include/dfgnn.h: dfgnn_gt_hyper_fwd_stats / dfgnn_gt_bwd_stats) ------------
+# Not part of the reference's module: FusedGTFunction_hyper (DFGNN/operators/fused_gtconv.py) takes this pair instead of
+# gt_hyper_forward / gt_backward when the whole batch runs on the matrix-core kernels -- same results, no attn_edge.
+# DFGNN_STATS=0 in the environment keeps the attn_edge pair everywhere (A/B runs).
+USE_STATS_PAIR = os.environ.get("DFGNN_STATS", "1") != "0"
+
+
+def gt_stats_pair_applies(row_ptr, col_ind, val, Q):
+    """True when gt_hyper_forward_stats / gt_backward_stats can serve this call: unit edge values and a block plan whose
+    ranges are all dense (dfgnn_gt_stats_applies)."""
+    if not (USE_STATS_PAIR and USE_BLOCK_PLAN) or Q.dim() != 3 or not Q.is_cuda:
+        return False
+    plan = get_plan_obj(row_ptr, col_ind, Q.size(-1), True)
+    return plan is not None and plan.stats_applies(Q.size(1)) and val_ptr(val) is None
+
+
+def gt_hyper_forward_stats(row_ptr, col_ind, Q, K, V):
+    """-> [out, row_max[m, h], row_sum[m, h]]: the training forward without attn_edge (call gt_stats_pair_applies first)."""
+    ext = _n.ext()
+    plan, meta, _ = get_plan(row_ptr, col_ind, Q.size(-1) if Q.dim() == 3 else 0, USE_BLOCK_PLAN)
+    if ext is not None and hasattr(ext, "gt_hyper_fwd_stats"):
+        return ext.gt_hyper_fwd_stats(row_ptr, col_ind, Q, K, V, plan or 0, meta or 0)
+    check_device(row_ptr=row_ptr, col_ind=col_ind)
+    check_contiguous(row_ptr=row_ptr, col_ind=col_ind)
+    check_dtype(torch.int32, row_ptr=row_ptr, col_ind=col_ind)
+    _check_qkv(Q, K, V)
+    m, nnz, h, f = _dims(row_ptr, col_ind, Q)
+    _check_graph(row_ptr, col_ind, Q.size(0))
+    with torch.cuda.device(Q.device):
+        out = torch.empty_like(Q)
+        row_max = torch.empty((m, h), dtype=torch.float32, device=Q.device)
+        row_sum = torch.empty((m, h), dtype=torch.float32, device=Q.device)
+        _n.check(_n.lib().dfgnn_gt_hyper_fwd_stats(m, nnz, h, f, ptr(row_ptr), ptr(col_ind), ptr(Q), ptr(K), ptr(V),
+                                                   ptr(row_max), ptr(row_sum), ptr(out), plan, meta,
+                                                   stream_ptr(Q.device)), "gt_hyper_forward_stats")
+    return [out, row_max, row_sum]
+
+
+def gt_backward_stats(row_ptr, col_ind, Q, K, V, row_max, row_sum, grad):
+    """-> [dQ, dK, dV] from the row statistics of gt_hyper_forward_stats (P is recomputed on the matrix cores)."""
+    ext = _n.ext()
+    plan, meta, _ = get_plan(row_ptr, col_ind, Q.size(-1) if Q.dim() == 3 else 0, USE_BLOCK_PLAN)
+    if ext is not None and hasattr(ext, "gt_bwd_stats"):
+        return ext.gt_bwd_stats(row_ptr, col_ind, Q, K, V, row_max, row_sum, grad, plan or 0, meta or 0)
+    check_device(row_ptr=row_ptr, col_ind=col_ind, row_max=row_max, row_sum=row_sum, grad=grad)
+    check_contiguous(row_ptr=row_ptr, col_ind=col_ind, row_max=row_max, row_sum=row_sum, grad=grad)
+    check_dtype(torch.int32, row_ptr=row_ptr, col_ind=col_ind)
+    check_dtype(torch.float32, row_max=row_max, row_sum=row_sum, grad=grad)
+    _check_qkv(Q, K, V)
+    check_feat3(Q=Q, grad=grad)
+    m, nnz, h, f = _dims(row_ptr, col_ind, Q)
+    _check_graph(row_ptr, col_ind, Q.size(0))
+    for name, t in (("row_max", row_max), ("row_sum", row_sum)):
+        if tuple(t.shape) != (m, h):
+            raise RuntimeError(f"{name} must have shape ({m}, {h}), got {tuple(t.shape)}")
+    with torch.cuda.device(Q.device):
+        dQ, dK, dV = torch.empty_like(Q), torch.empty_like(K), torch.empty_like(V)
+        _n.check(_n.lib().dfgnn_gt_bwd_stats(m, nnz, h, f, ptr(row_ptr), ptr(col_ind), ptr(Q), ptr(K), ptr(V), ptr(row_max),
+                                             ptr(row_sum), ptr(grad), ptr(dQ), ptr(dK), ptr(dV), plan, meta,
+                                             stream_ptr(Q.device)), "gt_backward_stats")
     return [dQ, dK, dV]
 
 

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define DFGNN_ABI_VERSION 8
+#define DFGNN_ABI_VERSION 9
 
 #define DFGNN_E_BADARG (-1)      /* negative size / NULL required pointer                      */
 #define DFGNN_E_UNSUPPORTED (-2) /* feature width outside the compiled range (f > 1024, or     */
@@ -61,7 +61,8 @@ const char *dfgnn_build_id(void);
  * fp32-equivalent arithmetic (operands as fp16 hi + lo halves under power-of-two scales, fp32 accumulation:
  * ~3 x 2^-24 relative error per product, that of an fp32 FMA chain).
  *   plan       device buffer of dfgnn_plan_ints(m, nnz) int32 (lists of ranges, build scratch and, for the
- *              matrix-core kernels, 2 bytes per edge: its row and column within its dense range)
+ *              matrix-core kernels, 2 bytes per edge -- its row and column within its dense range -- and two edge
+ *              bitmaps of 32 bytes per node: the out- and the in-neighbours of a node within its dense range)
  *   meta_host  host buffer of 12 int32 filled on return: num_fit, num_spill, max_fit_nodes,
  *              max_fit_edges, m, nnz, f, lds_budget, num_edge_global, num_dense, num_dense_wide (dense ranges of
  *              more than 128 nodes), coords_offset (int32 offset of the per-edge coordinates in `plan`)
@@ -119,6 +120,26 @@ int dfgnn_gt_bwd(int m, int nnz, int h, int f, const int *row_ptr, const int *co
                  const float *attn_edge, const float *grad_out, float *grad_edge, float *dQ,
                  float *dK, float *dV, const int *plan, const int *plan_meta,
                  dfgnn_stream_t stream);
+
+/* The statistics-saving form of the training pair above: what FusedGTFunction_hyper (DFGNN/operators/fused_gtconv.py:
+ * 79-158) needs from its forward is enough to rebuild the attention in the backward, not the attention itself.  Instead
+ * of attn_edge[h, nnz] (written by gt_hyper_forward, fused_gtconv_hyper.cu:146-149, read back by gt_backward,
+ * fused_gtconv_backward.cu:132-136: 8 h nnz bytes through HBM) the forward saves, per (row, head), the logit maximum and
+ * the sum of exponentials -- row_max, row_sum: fp32[m, h]; an empty row has row_max = -1e38, row_sum = 0 -- and the
+ * backward recomputes P_e = exp(s_e - row_max) / row_sum with one more Q K^T product on the matrix cores.
+ * Unit edge values only (there is no `val`), and only for batches that the matrix-core kernels cover completely:
+ * dfgnn_gt_stats_applies(m, nnz, h, f, plan_meta) == 1 (host-only; every range of the plan dense, nothing spilled);
+ * otherwise both calls return DFGNN_E_UNSUPPORTED and the caller uses dfgnn_gt_hyper_fwd / dfgnn_gt_bwd.  The sparse
+ * structure reaches these kernels through the plan's edge bitmaps alone: rows, CSC arrays, grad_edge are not needed.
+ * Results equal the attn_edge form's (same arithmetic for out; dQ, dK, dV to fp32 rounding). */
+int dfgnn_gt_stats_applies(int m, int nnz, int h, int f, const int *plan_meta);
+int dfgnn_gt_hyper_fwd_stats(int m, int nnz, int h, int f, const int *row_ptr, const int *col_ind, const float *Q,
+                             const float *K, const float *V, float *row_max, float *row_sum, float *out,
+                             const int *plan, const int *plan_meta, dfgnn_stream_t stream);
+int dfgnn_gt_bwd_stats(int m, int nnz, int h, int f, const int *row_ptr, const int *col_ind, const float *Q,
+                       const float *K, const float *V, const float *row_max, const float *row_sum,
+                       const float *grad_out, float *dQ, float *dK, float *dV, const int *plan, const int *plan_meta,
+                       dfgnn_stream_t stream);
 
 /* The two launches of the plan-less dfgnn_gt_bwd, exposed separately so each can be timed / profiled on its own
  * (dfgnn_gt_bwd == rows pass then cols pass on the same stream):
