@@ -2,12 +2,18 @@
 """bench.py -- headline benchmark: edges/s (fwd+bwd) of the fused GT conv ('hyper'), PATTERN-like
 batch bs=1024, dim=128, heads=1 (BASELINE.json configs[2]), on N GPUs of one node.
 
-One "step" = one pass of the hot path over one resident batch: GTConvFuse_hyper forward
-(writes out + attn_edge) + its autograd backward (dQ, dK, dV) at the operator boundary, exactly what
-DFGNN/script/train/train_batch_graph_timing.py times per layer in the reference.
+One "step" = one pass of the hot path over one resident batch: GTConvFuse_hyper forward + its autograd backward
+(dQ, dK, dV) at the operator boundary, exactly what DFGNN/script/train/train_batch_graph_timing.py times per layer in
+the reference.  On this batch (every member graph a dense range of the block plan, unit edge values)
+FusedGTFunction_hyper takes the statistics-saving pair: the forward writes out + two floats per (row, head) instead of
+attn_edge, the backward recomputes the attention (include/dfgnn.h: dfgnn_gt_hyper_fwd_stats / dfgnn_gt_bwd_stats); the
+attn_edge pair (the reference's form) is timed next to it as `secondary.attn_edge_pair`.
 Inputs (CSR/COO/CSC index arrays, Q, K, V, dO) are resident in HBM before the timed region.
 
-N > 1: one process per GPU (torch.distributed, RCCL).  Whole graphs are the shard unit and fwd+bwd needs no
+N > 1: one process per GPU (torch.distributed, RCCL).  Launched by the driver as `python -m torch.distributed.run
+--nproc-per-node N ... bench.py --gpus N` (RANK / LOCAL_RANK / WORLD_SIZE from the environment); run plainly as
+`python bench.py --gpus N` it starts its own N rank processes first -- before anything in this process touches a GPU --
+and rank 0's line is the output.  Whole graphs are the shard unit and fwd+bwd needs no
 data-path collective (dQ/dK/dV of a graph depend only on that graph).
   --scaling weak   (default, the driver contract): every rank owns its own bs=1024 batch; `value` = all edges / time.
   --scaling strong: the ONE seed-1 bs=1024 batch is cut into N shards of whole graphs, balanced by edge
@@ -34,7 +40,8 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md; ~6.3 TB/s is the measured copy rate)
-PMC_PROFILE = os.path.join("profiles", "r02_pmc_dense_kernels.json")  # HBM bytes per launch from rocprofv3 --pmc passes
+PMC_PROFILE = os.path.join("profiles", "r03_pmc_dense_kernels.json")  # HBM bytes per launch from rocprofv3 --pmc passes
+SETUP_STEPS = 20  # untimed steps inside Workload(): plan build, allocator pools, clocks (reported as "setup_steps")
 
 
 def parse():
@@ -52,11 +59,27 @@ def parse():
     # rehearsal only: "gloo" lets several ranks share ONE GPU (collectives on host tensors) to exercise the N > 1
     # code path on a single-GPU box; the driver's multi-GPU runs use the default (RCCL).
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"])
+    # no GPU work at all: ranks are started / joined, the process group comes up (gloo), the collectives the timed region
+    # uses are exercised on dummy numbers, rank 0 prints a line with "dry_run": true and no value -- what the CPU suite runs
+    ap.add_argument("--dry-run", action="store_true")
     return ap.parse_args()
 
 
+def algorithmic_bytes_stats(m, nnz, h, f):
+    """Compulsory HBM bytes per launch of the statistics-saving pair (each distinct input read once, each output written
+    once): what SURVEY.md 8(d) counts MINUS everything this pair no longer moves -- attn_edge (4 h nnz written, 4 h nnz
+    read), grad_edge (8 h nnz), rows / col_ind / val / the CSC arrays -- PLUS what it moves instead: the row statistics
+    (2 floats per (row, head), written once and read once) and the plan's edge bitmaps (32 bytes per node: the out-edges;
+    the multi-head backward also reads the in-edges)."""
+    D = h * f
+    return {
+        "gt_hyper_fwd_stats": 16 * m * D + 8 * m * h + 32 * m,
+        "gt_bwd_stats": 28 * m * D + 8 * m * h + 32 * m * (2 if h > 1 else 1),
+    }
+
+
 def algorithmic_bytes(m, nnz, h, f):
-    """Compulsory HBM bytes per launch (each distinct input read once, each output written once);
+    """Compulsory HBM bytes per launch of the attn_edge pair (each distinct input read once, each output written once);
     SURVEY.md 8(d), split per kernel (DESIGN.md 'Roofline')."""
     D = h * f
     return {
@@ -109,7 +132,7 @@ class Workload:
         # part of setting the workload up, like the preprocessing above: the first call builds the block plan, the next few
         # fill the allocator's pools and bring host and device clocks up (the first ~30 operator calls of a process run
         # slower, see tests/tools/bench_configs.py)
-        for _ in range(20):
+        for _ in range(SETUP_STEPS):
             self.step()
         torch.cuda.synchronize(dev)
 
@@ -119,13 +142,57 @@ class Workload:
         return torch.autograd.grad(out, (self.Q, self.K, self.V), self.dO)
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start N rank processes of this script (RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* in their environment, a free local port) and return the largest exit code.  Nothing in THIS
+    process has touched a GPU yet (importing torch does not), and nothing does: it only waits.  Rank 0 prints the line."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    codes = [p.wait() for p in procs]
+    return max(abs(c) for c in codes)
+
+
+def dry_run(args, world, rank):
+    """--dry-run: the launch / rendezvous / collective plumbing of an N-rank run without a GPU."""
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+        t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        e = torch.tensor([rank + 1], dtype=torch.int64)
+        dist.all_reduce(e)
+        dist.barrier()
+        assert int(t.item()) == world and int(e.item()) == world * (world + 1) // 2
+    if rank == 0:
+        print(json.dumps({"metric": "edges/s (fwd+bwd) fused GT conv, PATTERN bs=1024 dim=128", "value": None, "unit": "edges/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "dry_run": True,
+                          "scaling": args.scaling if world > 1 else "weak"}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and rank == 0:
-        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    if world != args.gpus:
+        if rank == 0:
+            print(f"[bench] --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks: refusing to report a line "
+                  f"for a job of another size", file=sys.stderr)
+        sys.exit(2)
+    if args.dry_run:
+        return dry_run(args, world, rank)
     assert torch.cuda.is_available(), "bench.py needs a GPU (the fused kernels have no CPU fallback)"
     if args.dist_backend == "gloo":
         local_rank = local_rank % max(1, torch.cuda.device_count())
@@ -259,6 +326,18 @@ def main():
     plan, plan_meta, _ = get_plan(W.row_ptr, W.col_ind, f, fused_gtconv.USE_BLOCK_PLAN)
     VP = val_ptr(W.val)  # NULL for unit edge values, exactly as the binding passes it (fused_gtconv.py)
 
+    uses_stats = fused_gtconv.gt_stats_pair_applies(W.row_ptr, W.col_ind, W.val, W.Q)  # what the timed step launches
+    with torch.no_grad():
+        rmax, rsum = torch.empty(m, h, device=dev), torch.empty(m, h, device=dev)
+
+    def fwd_stats_call():
+        return L.dfgnn_gt_hyper_fwd_stats(m, nnz, h, f, P(W.row_ptr), P(W.col_ind), P(W.Q), P(W.K), P(W.V), P(rmax), P(rsum),
+                                          P(out), plan, plan_meta, stream)
+
+    def bwd_stats_call():
+        return L.dfgnn_gt_bwd_stats(m, nnz, h, f, P(W.row_ptr), P(W.col_ind), P(W.Q), P(W.K), P(W.V), P(rmax), P(rsum),
+                                    P(W.dO), P(dQ), P(dK), P(dV), plan, plan_meta, stream)
+
     def fwd_call(vp):
         return lambda: L.dfgnn_gt_hyper_fwd(m, nnz, h, f, P(W.row_ptr), P(W.col_ind), P(W.rows), vp, P(W.Q), P(W.K), P(W.V),
                                             P(attn), None, P(out), plan, plan_meta, stream)
@@ -274,12 +353,17 @@ def main():
         return run
 
     reps = max(10, args.steps)
-    kernel_us = {"gt_hyper_fwd": ev_us(checked(fwd_call(VP)), reps), "gt_bwd": ev_us(checked(bwd_call(VP)), reps)}
+    attn_us = {"gt_hyper_fwd": ev_us(checked(fwd_call(VP)), reps), "gt_bwd": ev_us(checked(bwd_call(VP)), reps)}
+    attn_bytes = algorithmic_bytes(m, nnz, h, f)
+    if uses_stats:
+        kernel_us = {"gt_hyper_fwd_stats": ev_us(checked(fwd_stats_call), reps), "gt_bwd_stats": ev_us(checked(bwd_stats_call), reps)}
+        abytes = algorithmic_bytes_stats(m, nnz, h, f)
+    else:
+        kernel_us, abytes = attn_us, attn_bytes
     # the same two launches with the edge values passed explicitly (val != NULL): the matrix-core kernels step aside and
     # every product is an fp32 FMA on the VALU (the LDS-resident edge-walking kernels) -- the plain-f32 reference point
     valu_us = {"gt_hyper_fwd": ev_us(checked(fwd_call(P(W.val))), reps), "gt_bwd": ev_us(checked(bwd_call(P(W.val))), reps)}
-    abytes = algorithmic_bytes(m, nnz, h, f)
-    dom = max(("gt_hyper_fwd", "gt_bwd"), key=kernel_us.get)  # the launches the timed step actually runs
+    dom = max(kernel_us, key=kernel_us.get)  # the launches the timed step actually runs
     achieved = abytes[dom] / (kernel_us[dom] * 1e-6) / 1e9
     # HBM bytes per launch from PMC counters (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc passes over this exact
     # workload and build, committed under profiles/): bench.py cannot collect counters itself, so the figure is quoted
@@ -290,7 +374,8 @@ def main():
         import dfgnn_native
         if (prof.get("m") == m and prof.get("nnz") == nnz and prof.get("h") == h and prof.get("f") == f and
                 prof.get("build_id") == dfgnn_native.build_id()):
-            key = {"gt_hyper_fwd": "gt_dense_fwd_kernel", "gt_bwd": "gt_dense_bwd_kernel"}[dom]
+            key = {"gt_hyper_fwd": "gt_dense_fwd_kernel", "gt_bwd": "gt_dense_bwd_kernel",
+                   "gt_hyper_fwd_stats": "gt_dense_fwd_stats_kernel", "gt_bwd_stats": "gt_dense_bwd_stats_kernel"}[dom]
             traffic = int(prof["traffic"][key]["total_bytes"])
             traffic_src = PMC_PROFILE + (" (library build %s)" % prof.get("build_id", "?"))
     except Exception:
@@ -320,8 +405,8 @@ def main():
                                   "passed explicitly, so the matrix-core kernels step aside)",
                           "fwd_us": round(valu_us["gt_hyper_fwd"], 2), "bwd_us": round(valu_us["gt_bwd"], 2),
                           "edges_per_s": nnz / (valu_step_us * 1e-6),
-                          "frac_fwd": round(abytes["gt_hyper_fwd"] / (valu_us["gt_hyper_fwd"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
-                          "frac_bwd": round(abytes["gt_bwd"] / (valu_us["gt_bwd"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}}
+                          "frac_fwd": round(attn_bytes["gt_hyper_fwd"] / (valu_us["gt_hyper_fwd"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                          "frac_bwd": round(attn_bytes["gt_bwd"] / (valu_us["gt_bwd"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}}
 
     # ---- secondary figures (never part of `value`), rank 0 at N = 1 only ----------------------------------------
     secondary = None
@@ -352,6 +437,9 @@ def main():
 
         def raw_step():  # the launches of the timed step as explicit operator calls (no autograd bookkeeping)
             with torch.no_grad():
+                if uses_stats:
+                    o, mx_, sm_ = fused_gtconv.gt_hyper_forward_stats(W.row_ptr, W.col_ind, W.Q, W.K, W.V)
+                    return fused_gtconv.gt_backward_stats(W.row_ptr, W.col_ind, W.Q, W.K, W.V, mx_, sm_, W.dO)
                 o, at = fused_gtconv.gt_hyper_forward(W.row_ptr, W.col_ind, W.rows, W.val, W.col_ptr, W.row_ind, W.val_idx,
                                                       W.smem, W.Q, W.K, W.V)
                 return fused_gtconv.gt_backward(W.row_ptr, W.col_ind, W.rows, W.val, W.col_ptr, W.row_ind, W.val_idx, W.smem,
@@ -359,6 +447,10 @@ def main():
 
         graphed = GraphedStep(raw_step)
         secondary = {
+            # the reference's form of the pair (attn_edge written by the forward, read by the backward), same batch, same
+            # launches as round 2's headline; SURVEY.md 8(d) bytes
+            "attn_edge_pair": {k: {"avg_us": round(v, 2), "algorithmic_bytes": attn_bytes[k],
+                                   "frac": round(attn_bytes[k] / (v * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)} for k, v in attn_us.items()},
             "gat_train": {"fwd_us": round(gat_f, 1), "bwd_us": round(gat_b, 1),
                           "edges_per_s": nnz / ((gat_f + gat_b) * 1e-6)},
             "preprocess_per_batch_ms": {
@@ -416,10 +508,13 @@ def main():
         line = {
             "metric": "edges/s (fwd+bwd) fused GT conv, PATTERN bs=1024 dim=128",
             "value": value, "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "setup_steps": SETUP_STEPS,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": args.scaling if world > 1 else "weak",
             "vs_baseline": None, "dtype": "f32", "arithmetic": arithmetic, "data": "synthetic",
             "config": {"workload": f"GT conv 'hyper' fwd+bwd, PATTERN-like batch bs={args.batch_size} "
                                    f"dim={args.dim} heads={h} (BASELINE.json configs[2])",
+                       "training_pair": "row statistics (dfgnn_gt_hyper_fwd_stats / dfgnn_gt_bwd_stats)" if uses_stats
+                       else "attn_edge (dfgnn_gt_hyper_fwd / dfgnn_gt_bwd)",
                        "nodes_per_gpu": m, "edges_per_gpu": nnz, "total_edges": total_edges,
                        "parallelism": (f"graph-sharded x{world} ({args.scaling} scaling), no data-path collective")},
             "roofline": roofline, "cpu_baseline": cpu,

@@ -10,8 +10,8 @@
 // the edges, not their positions) comes from the plan's bitmaps (plan.hip: mask / maskT, 32 bytes per node), fetched by
 // each lane for its own rows: no edge list, no row pointers, no byte map, no scatter.
 //   forward :  dense_fwd_body / gt_dense_fwd_lean_kernel / dense_fwd_heads_body with STATS
-//   backward:  one head      -- <= 128 nodes: dense_bwd_rc_body (V, K, dO, Q: every image once, dQ straight from the dS
-//                               accumulators); larger: dense_bwd_wide_body / dense_bwd_body with RECOMP (K staged again)
+//   backward:  one head      -- <= 128 nodes: dense_bwd_rc2_body ([dO|V], [Q|K], [dO|P]: images staged in pairs, dQ straight
+//                               from the dS accumulators); larger: dense_bwd_wide_body / dense_bwd_body with RECOMP (K again)
 //              multi-head    -- dense_bwd_heads2_body (ranges of <= 160 nodes, heads of 16 / 32 / 64 features: every head
 //                               of a range in one workgroup, no P / dS tile); other shapes per (range, head) as above
 // gt_hyper_forward -> [out, attn_edge] (the reference's signature) stays what it was for direct callers; the autograd
@@ -30,7 +30,7 @@
 #include "dfgnn_dense_heads2.hpp"
 #include "dfgnn_dense_fwd.hpp"
 #include "dfgnn_dense_bwd.hpp"
-#include "dfgnn_dense_bwd_rc.hpp"
+#include "dfgnn_dense_bwd_rc2.hpp"
 
 namespace dfgnn {
 
@@ -86,13 +86,13 @@ template <int F>
 __global__ __launch_bounds__(kDenseThreads) void gt_dense_bwd_stats_kernel(
     Csr g, const int *__restrict__ fit, const float *__restrict__ Q, const float *__restrict__ K,
     const float *__restrict__ V, const float *__restrict__ stat_max, const float *__restrict__ stat_sum,
-    const float *__restrict__ dO, float *__restrict__ dQ, float *__restrict__ dK, float *__restrict__ dV) {
+    const float *__restrict__ dO, float *__restrict__ dQ, float *__restrict__ dK, float *__restrict__ dV, int heads2) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int range = blockIdx.x, head = blockIdx.y;
   const int n0 = fit[2 * range], n1 = fit[2 * range + 1] & kPlanRangeMask;
   const int n = n1 - n0;
   if constexpr (F == 16 || F == 32 || F == 64) {
-    if (g.h > 1 && dense_heads_ok(F, g.h) && n <= kDenseWideRows) {
+    if (heads2 && n <= kDenseWideRows) {  // (heads2: the launcher's choice, uniform over the grid)
       if (head != 0) return;
       if (n <= kDenseChunkRows) dense_bwd_heads2_body<F, kDenseChunkRows>(lds, g, n0, n, Q, K, V, dO, stat_max, stat_sum, dQ, dK, dV);
       else dense_bwd_heads2_body<F, kDenseWideRows>(lds, g, n0, n, Q, K, V, dO, stat_max, stat_sum, dQ, dK, dV);
@@ -103,11 +103,7 @@ __global__ __launch_bounds__(kDenseThreads) void gt_dense_bwd_stats_kernel(
   st.edge_max = stat_max;
   st.edge_sum = stat_sum;
   if (n <= kDenseChunkRows)
-#ifdef DFGNN_RC_KTWICE  // A/B builds: the attn_edge body's phase order with one more K image in front (five image phases)
-    dense_bwd_body<F, kDenseChunkRows, 1, false, true>(lds, g, n0, n, 0, 0, head, Q, K, V, nullptr, dO, dQ, dK, dV, st);
-#else
-    dense_bwd_rc_body<F>(lds, g, n0, n, head, Q, K, V, stat_max, stat_sum, dO, dQ, dK, dV);
-#endif
+    dense_bwd_rc2_body<F>(lds, g, n0, n, head, Q, K, V, stat_max, stat_sum, dO, dQ, dK, dV);
   else if (n <= kDenseWideRows)
     dense_bwd_wide_body<F, kDenseWideRows, DFGNN_RING160, 64, true>(lds, g, n0, n, 0, 0, head, Q, K, V, nullptr, dO, dQ, dK, dV,
                                                                     stat_max, stat_sum);
@@ -123,6 +119,12 @@ static int dispatch_dense_stats(int f, Fn &&fn) {
   if (f == 64) return fn(std::integral_constant<int, 64>{});
   if (f == 128) return fn(std::integral_constant<int, 128>{});
   return kErrUnsupported;
+}
+
+// widest head the all-heads-in-one-workgroup backward takes (DFGNN_HEADS2_MAXF in the environment: diagnostic switch)
+static int heads2_max_f() {
+  static const int v = [] { const char *e = getenv("DFGNN_HEADS2_MAXF"); return e ? atoi(e) : 16; }();
+  return v;
 }
 
 static bool stats_lean_enabled() {
@@ -163,11 +165,14 @@ int launch_gt_dense_bwd_stats(const Csr &g_in, const Plan &p, const float *Q, co
   g.mask = p.mask();
   g.maskT = p.maskT();
   const dim3 grid(p.num_dense, g.h);
+  // multi-head: every head of a range of <= 160 nodes in one workgroup (dense_bwd_heads2_body) for heads of at most
+  // kHeads2MaxF features; wider heads run per (range, head) on the single-head bodies
+  const int heads2 = (g.h > 1 && dense_heads_ok(g.f, g.h) && g.f <= heads2_max_f()) ? 1 : 0;
   return dispatch_dense_stats(g.f, [&](auto fc) {
     constexpr int F = decltype(fc)::value;
     if (int rc = set_max_lds_cached(gt_dense_bwd_stats_kernel<F>)) return rc;
     gt_dense_bwd_stats_kernel<F><<<grid, kDenseThreads, kLdsBytes, s>>>(g, p.fit(), Q, K, V, stat_max, stat_sum, grad_out, dQ, dK,
-                                                                        dV);
+                                                                        dV, heads2);
     return launch_status();
   });
 }

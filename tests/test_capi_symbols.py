@@ -29,10 +29,10 @@ def test_loader_signatures_cover_header():
                                                        "dfgnn_plan_ints", "dfgnn_plan_applies", "dfgnn_preprocess_ws_bytes")]
     assert sorted(dfgnn_native.SIGNATURES) == compute
     lib = dfgnn_native.lib()
-    assert lib.dfgnn_abi_version() == 8
+    assert lib.dfgnn_abi_version() == 9
     assert b"bad argument" in lib.dfgnn_error_string(-1)
     assert b"unsupported" in lib.dfgnn_error_string(-2)
-    assert lib.dfgnn_plan_ints(10, 40) >= 12 + 7 * 10 + 4 + 20  # header + lists + scratch (+ rocPRIM temporary storage) + edge coordinates
+    assert lib.dfgnn_plan_ints(10, 40) >= 12 + 7 * 10 + 4 + 20 + 2 * 8 * 10  # header + lists + scratch (+ rocPRIM temporary storage) + edge coordinates + the two edge bitmaps
 
 
 def test_plan_fallback_predicate():
@@ -90,7 +90,7 @@ def test_torch_extension_binds_the_same_c_abi():
     assert "dfgnn_gt_hyper_fwd" in used and "dfgnn_gt_bwd" in used and "dfgnn_gat_softmax_fwd" in used
     assert set(used) <= set(_declared())
     ext = dfgnn_native.ext()
-    assert ext is not None and ext.abi_version() == 8 and ext.build_id() == dfgnn_native.source_hash()
+    assert ext is not None and ext.abi_version() == 9 and ext.build_id() == dfgnn_native.source_hash()
 
 
 def test_graft_entry_build_passes():

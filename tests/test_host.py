@@ -235,3 +235,29 @@ def test_dotgat_baseline_restates_dgl_dotgatconv():
     hn = h.numpy()
     ref = oracle.gt_forward(row_ptr.numpy(), col_ind.numpy(), val.numpy(), hn, hn, hn)
     assert np.abs(out.numpy() - ref).max() < 1e-5
+
+
+def test_bench_gpus_n_starts_its_own_ranks():
+    """`python bench.py --gpus N` without a launcher (no WORLD_SIZE in the environment) starts N rank processes itself --
+    before anything touches a GPU -- and rank 0's line says n_gpus = N; a launcher that started another number of ranks
+    than --gpus is refused.  (--dry-run: rendezvous and collectives over gloo, no kernels; the GPU suite runs the real
+    line.)"""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--steps", "3"],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["dry_run"] is True and line["steps"] == 3
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry-run"], env=env, capture_output=True, text=True,
+                         timeout=600)
+    assert one.returncode == 0 and json.loads(one.stdout.strip().splitlines()[-1])["n_gpus"] == 1
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--dry-run"],
+                         env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=600)
+    assert bad.returncode != 0 and "refusing" in bad.stderr
