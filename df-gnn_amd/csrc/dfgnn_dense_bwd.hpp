@@ -342,7 +342,7 @@ __device__ __forceinline__ void dense_bwd_body(float *lds, const Csr &g, int n0,
         sinv = (ssum != 0.f) ? 1.f / ssum : 0.f;
       }
       hx8 qh[KT], ql[KT];
-      float qinv = 1.f;
+      float qinv = 1.f, lsum = 0.f;  // lsum: this lane's part of the row's sum of exponentials
 #pragma unroll
       for (int jc = 0; jc < NBLK; ++jc) {
         if (jc > 0) image_prefetch(Kb, jc * CW, n);
@@ -380,14 +380,23 @@ __device__ __forceinline__ void dense_bwd_body(float *lds, const Csr &g, int n0,
             const int ug = jc * U + u;
             const unsigned bits = (mwd[ug / 2] >> (16 * (ug & 1) + 4 * L.mq)) & 0xFu;
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-              Pr[jc][u][r] = ((bits >> r) & 1u) ? __builtin_amdgcn_exp2f(fmaf(S[u][r], c2, -b2)) * sinv : 0.f;
+            for (int r = 0; r < 4; ++r) {
+              Pr[jc][u][r] = ((bits >> r) & 1u) ? __builtin_amdgcn_exp2f(fmaf(S[u][r], c2, -b2)) : 0.f;
+              lsum += Pr[jc][u][r];
+            }
           }
         } else {
 #pragma unroll
           for (int u = 0; u < U; ++u) Pr[jc][u] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
       }
+      // normalised by their own row sum (see dense_bwd_rc2_body): sum_j P_ij = 1 for the P that is differentiated
+      lsum = xor16_32_sum(lsum);
+      const float linv = (sinv != 0.f && lsum > 0.f) ? 1.f / lsum : 0.f;
+#pragma unroll
+      for (int jc = 0; jc < NBLK; ++jc)
+#pragma unroll
+        for (int u = 0; u < U; ++u) Pr[jc][u] *= linv;
     }
 #pragma unroll
     for (int jc = 0; jc < NBLK; ++jc) {

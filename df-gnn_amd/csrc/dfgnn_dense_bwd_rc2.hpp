@@ -186,19 +186,27 @@ __device__ __forceinline__ void dense_bwd_rc2_body(float *lds, const Csr &g, int
     if (row_wave) {
       dense_rows_mma_strip<F, U>(P, bhi, blo, n, qh, ql, L);  // S (x the two scales)
       const float c2 = (sa.inv * sb.inv) * kLog2e;
-      float t = 0.f;
+      // The exponentials are normalised by THEIR OWN row sum (the forward's l_i belongs to the forward's rounding of S:
+      // with logits of +-100 the two differ by 1e-5 relative, and sum_j P_ij = 1 is what the softmax Jacobian assumes);
+      // the forward's m_i only has to be near the maximum.  sinv just says whether the row has edges at all.
+      float t = 0.f, l = 0.f;
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const unsigned bits = (mwd[u / 2] >> (16 * (u & 1) + 4 * L.mq)) & 0xFu;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float p = ((bits >> r) & 1u) ? __builtin_amdgcn_exp2f(fmaf(P[u][r], c2, -smx)) * sinv : 0.f;
+          const float p = ((bits >> r) & 1u) ? __builtin_amdgcn_exp2f(fmaf(P[u][r], c2, -smx)) : 0.f;
           P[u][r] = p;
+          l += p;
           dS[u][r] *= dpc;
           t = fmaf(p, dS[u][r], t);
         }
       }
-      t = xor16_32_sum(t);  // a row lives on 4 lanes of this wave
+      l = xor16_32_sum(l);  // a row lives on 4 lanes of this wave
+      const float linv = (sinv != 0.f && l > 0.f) ? 1.f / l : 0.f;
+      t = xor16_32_sum(t) * linv;
+#pragma unroll
+      for (int u = 0; u < U; ++u) P[u] *= linv;
 #pragma unroll
       for (int u = 0; u < U; ++u)
 #pragma unroll

@@ -270,21 +270,32 @@ __device__ __forceinline__ void dense_bwd_heads2_body(float *lds, const Csr &g, 
     // sweep 1: P (kept), t_i = sum_j P dP.  Every tile of the padded range, no branches (the images are zero past the
     // range and the bitmaps have no bits there): straight-line code lets the MFMA chains of one tile run under the vector
     // work of another.
+    // The exponentials are normalised by THEIR OWN row sum (the forward's l_i belongs to the forward's rounding of S: with
+    // logits of +-100 the two differ by 1e-5 relative, and sum_j P_ij = 1 is what the softmax Jacobian assumes); the col
+    // pass gets 1 / l from here as well.  The forward's m_i only has to be near the maximum.
     f32x4 P[U];
-    float t = 0.f;
+    float t = 0.f, l = 0.f;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const f32x4 sacc = rows_tile(ahi, alo, u, c0, qh, ql, L);
       const f32x4 dacc = rows_tile(bhi, blo, u, c0, dh, dl, L);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float p = edge_and(__builtin_amdgcn_exp2f(fmaf(sacc[r], c2, -b2)) * sinv, ws, u, r);
+        const float p = edge_and(__builtin_amdgcn_exp2f(fmaf(sacc[r], c2, -b2)), ws, u, r);
         P[u][r] = p;
+        l += p;
         t = fmaf(p, dacc[r] * dpc, t);
       }
     }
-    t = xor16_32_sum(t);  // a row lives on 4 lanes of this wave
-    if (L.mq == 0) tarr[q * NP + i] = t;
+    l = xor16_32_sum(l);  // a row lives on 4 lanes of this wave
+    const float linv = (sinv != 0.f && l > 0.f) ? 1.f / l : 0.f;
+    t = xor16_32_sum(t) * linv;
+#pragma unroll
+    for (int u = 0; u < U; ++u) P[u] *= linv;
+    if (L.mq == 0) {
+      tarr[q * NP + i] = t;
+      sinvl[q * NP + i] = linv;
+    }
     // sweep 2: dP again, dS = P (dP - t) k-block by k-block -> dQ^T = K^T dS^T
     f32x4 acc[FTH], aux[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll

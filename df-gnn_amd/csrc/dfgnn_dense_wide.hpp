@@ -183,13 +183,25 @@ __device__ __forceinline__ void dense_bwd_wide_body(float *lds, const Csr &g, in
         const LaneIds L = lane_ids();
         h16 *trow = Tb + (strip * 16 + L.mi) * TB + 4 * L.mq;
         const float b = smx[s];
+        // normalised by their own row sum (see dense_bwd_rc2_body): sum_j P_ij = 1 for the P that is differentiated
+        float lsum = 0.f;
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           const unsigned bits = (mwd[s][u / 2] >> (16 * (u & 1) + 4 * L.mq)) & 0xFu;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            S[s][u][r] = ((bits >> r) & 1u) ? fast_exp(S[s][u][r] - b) : 0.f;
+            lsum += S[s][u][r];
+          }
+        }
+        lsum = xor16_32_sum(lsum);
+        const float linv = (sinv[s] != 0.f && lsum > 0.f) ? 1.f / lsum : 0.f;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
           hx4 h4, l4;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float p = ((bits >> r) & 1u) ? fast_exp(S[s][u][r] - b) * sinv[s] : 0.f;
+            const float p = S[s][u][r] * linv;
             const h16 hh = (h16)(p * kUnitScale);
             h4[r] = hh;
             l4[r] = (h16)fmaf(p, kUnitScale, -(float)hh);
