@@ -49,27 +49,63 @@ def ptr(t):
     return t.data_ptr() if t is not None else None
 
 
+class _KeyedCache:
+    """A small LRU keyed by what a tensor IS -- (data_ptr, numel, version counter) -- rather than by the Python object that
+    wraps it: a re-wrapped tensor (.detach(), a view of the same memory, a tuple rebuilt by a data loader around the same
+    storages) finds the entry its first wrapper made.  Each entry keeps a reference to the tensors of its key, so the
+    memory behind a key cannot be freed and handed to other data while the entry lives; the LRU bound (DFGNN_CACHE_ENTRIES,
+    default 16) is what that costs."""
+
+    def __init__(self, entries=None):
+        import collections
+        import os
+        self.entries = entries or int(os.environ.get("DFGNN_CACHE_ENTRIES", "16"))
+        self.d = collections.OrderedDict()
+
+    @staticmethod
+    def key_of(*tensors, extra=()):
+        return tuple((t.data_ptr(), t.numel(), t._version, t.dtype, t.device.index) for t in tensors) + tuple(extra)
+
+    def get(self, key):
+        hit = self.d.get(key)
+        if hit is not None:
+            self.d.move_to_end(key)
+            return hit[0]
+        return None
+
+    def put(self, key, value, *keep_alive):
+        self.d[key] = (value, keep_alive)
+        self.d.move_to_end(key)
+        while len(self.d) > self.entries:
+            self.d.popitem(last=False)
+        return value
+
+
+_unit_cache = _KeyedCache()
+_plan_cache = _KeyedCache()
+_rows_cache = _KeyedCache()
+
+
 def val_ptr(val):
     """Edge values for the C ABI: NULL when they are all ones (include/dfgnn.h: "NULL means all ones"), which is
     what every reference flow passes (A.val of an unweighted adjacency, DFGNN/layers/util.py:82-142) and lets the
     kernels skip the per-edge multiply.  The test runs once per tensor version (one device reduction + sync)."""
     if val is None:
         return None
-    cached = getattr(val, "_dfgnn_unit", None)
-    if cached is None or cached[0] != val._version:
-        # Preprocessing marks the arrays it creates (DFGNN/layers/util.py:_unit_val), so flows that follow the
-        # reference never get here; a foreign tensor is tested once (one reduction + host sync), which cannot happen
-        # inside a stream capture.
+    cached = getattr(val, "_dfgnn_unit", None)   # preprocessing marks the arrays it creates (DFGNN/layers/util.py:_unit_val)
+    if cached is not None and cached[0] == val._version:
+        return None if cached[1] else val.data_ptr()
+    key = _KeyedCache.key_of(val)
+    unit = _unit_cache.get(key)
+    if unit is None:
+        # a foreign tensor is tested once per (memory, version) -- one reduction + host sync, which cannot happen inside
+        # a stream capture -- whatever Python object wraps it the next time
         if val.is_cuda and torch.cuda.is_current_stream_capturing():
             raise RuntimeError("edge values of unknown content inside a HIP-graph capture: run the operator once before "
                                "capturing (or create `val` through DFGNN.layers.preprocess_*), so that the all-ones test "
-                               "is cached on the tensor")
-        cached = (val._version, bool((val == 1).all().item()) if val.numel() else True)
-        try:
-            val._dfgnn_unit = cached
-        except AttributeError:
-            pass
-    return None if cached[1] else val.data_ptr()
+                               "is cached")
+        unit = _unit_cache.put(key, bool((val == 1).all().item()) if val.numel() else True, val)
+    return None if unit else val.data_ptr()
 
 
 # ---- block plan cache -----------------------------------------------------------------------------
@@ -123,6 +159,10 @@ def build_plan(indptr, indices, f):
 
     import dfgnn_native as _n
     m, nnz = indptr.size(0) - 1, indices.size(0)
+    ext = _n.ext()
+    if ext is not None and hasattr(ext, "plan_build"):  # torch C++ binding: allocation + call without ctypes marshalling
+        buf, meta_l = ext.plan_build(indptr, indices, int(f))
+        return BlockPlan(buf, (ctypes.c_int * 12)(*meta_l), (indices.data_ptr(), nnz, indptr._version, indices._version, f))
     L = _n.lib()
     with torch.cuda.device(indptr.device):
         buf = torch.empty(int(L.dfgnn_plan_ints(m, nnz)), dtype=torch.int32, device=indptr.device)
@@ -136,13 +176,14 @@ def get_plan_obj(indptr, indices, f, enable=True):
     """The BlockPlan object behind get_plan (None when there is none)."""
     if get_plan(indptr, indices, f, enable)[0] is None:
         return None
-    return indptr.__dict__["_dfgnn_plans"][f]
+    return _plan_cache.get(_KeyedCache.key_of(indptr, indices, extra=(f,)))
 
 
 def get_plan(indptr, indices, f, enable=True):
-    """Plan of (indptr, indices, f), built on first use and cached on the indptr tensor object -- the
-    reference's preprocess_* tuples keep that tensor alive across the layers / epochs that reuse a batch
-    (DFGNN/layers/util.py:82-142), so the plan is built once per batch structure.
+    """Plan of (indptr, indices, f), built on first use and cached by the identity of the two arrays' MEMORY (address,
+    length, version counter; _KeyedCache) -- the reference's preprocess_* tuples keep those arrays alive across the layers /
+    epochs that reuse a batch (DFGNN/layers/util.py:82-142), so the plan is built once per batch structure, also when
+    the tensors reach the operator re-wrapped (.detach(), views, rebuilt tuples).
     Returns (plan_ptr, meta_ptr, needs_edge_scratch) for the C ABI, or (None, None, False)."""
     if not enable or f <= 0 or f % 4 != 0 or indices.dim() != 1 or indptr.dim() != 1 or indices.size(0) == 0:
         return None, None, False
@@ -151,12 +192,14 @@ def get_plan(indptr, indices, f, enable=True):
         return None, None, False  # (the binding's argument checks raise the matching error right after)
     if indices.size(0) < 8 * (indptr.size(0) - 1):
         return None, None, False  # low-degree graphs take the row-per-lane-group kernels (capi.hip:low_degree)
-    key = (indices.data_ptr(), indices.size(0), indptr._version, indices._version, f)
-    cache = indptr.__dict__.setdefault("_dfgnn_plans", {})
-    plan = cache.get(f)
-    if plan is None or plan.key != key:
-        plan = build_plan(indptr, indices, f)
-        cache[f] = plan
+    key = _KeyedCache.key_of(indptr, indices, extra=(f,))
+    plan = _plan_cache.get(key)
+    if plan is None:
+        plan = _plan_cache.put(key, build_plan(indptr, indices, f), indptr, indices)
+        try:  # (also reachable from the tensor object, for tests and tools that inspect a plan: row_ptr._dfgnn_plans[f])
+            indptr.__dict__.setdefault("_dfgnn_plans", {})[f] = plan
+        except AttributeError:
+            pass
     if plan.num_fit == 0:
         return None, None, False
     return plan.ptrs() + (plan.num_edge_global > 0,)
@@ -167,11 +210,15 @@ def get_rows(row_ptr, nnz):
     cached on it like the plan.  The reference's gat_forward / gat_backward take CSR only
     (DFGNN/src/fused_gatconv/fused_gatconv.cpp:11-14, 291-300); the matrix-core kernels walk the edges by (row, col)
     pairs, so the binding derives the row ids next to the plan -- preprocessing, once per batch structure."""
-    cached = row_ptr.__dict__.get("_dfgnn_rows")
-    if cached is None or cached[0] != (row_ptr._version, nnz):
+    key = _KeyedCache.key_of(row_ptr, extra=(nnz,))
+    rows = _rows_cache.get(key)
+    if rows is None:
         deg = (row_ptr[1:] - row_ptr[:-1]).long()
         rows = torch.repeat_interleave(torch.arange(deg.numel(), dtype=torch.int32, device=row_ptr.device), deg,
                                        output_size=nnz)
-        cached = ((row_ptr._version, nnz), rows)
-        row_ptr.__dict__["_dfgnn_rows"] = cached
-    return cached[1]
+        _rows_cache.put(key, rows, row_ptr)
+        try:  # (mirror on the tensor object, for tests that inspect it)
+            row_ptr.__dict__["_dfgnn_rows"] = (key, rows)
+        except AttributeError:
+            pass
+    return rows

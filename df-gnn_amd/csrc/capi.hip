@@ -2,6 +2,7 @@
 // Argument validation + dispatch only; no allocation, no synchronisation.
 #include "../../include/dfgnn.h"
 #include "dfgnn_launch.hpp"
+#include "dfgnn_errstr.h"
 
 #include <mutex>
 #include <set>
@@ -81,13 +82,8 @@ int dfgnn_plan_applies(int m, int nnz, int h, int f, const int *plan_meta) {
 const char *dfgnn_build_id(void) { return DFGNN_SRC_HASH; }
 
 const char *dfgnn_error_string(int code) {
-  if (code == 0) return "success";
-  if (code == DFGNN_E_BADARG) return "dfgnn: bad argument (negative size or NULL required pointer)";
-  if (code == DFGNN_E_UNSUPPORTED)
-    return "dfgnn: unsupported shape (f > 1024, f % 4 != 0 with f > 256, or h > 65535) or, for the statistics-saving pair, a "
-           "batch that the matrix-core kernels do not cover (dfgnn_gt_stats_applies)";
-  if (code > 0) return hipGetErrorString(static_cast<hipError_t>(code));
-  return "dfgnn: unknown error";
+  if (const char *text = dfgnn_static_error_string(code)) return text;
+  return hipGetErrorString(static_cast<hipError_t>(code));
 }
 
 int dfgnn_gt_hyper_fwd(int m, int nnz, int h, int f, const int *row_ptr, const int *col_ind, const int *rows,

@@ -1,7 +1,9 @@
-"""Loader for libdfgnn.so -- the C-ABI HIP library (include/dfgnn.h).
+"""Loader for libdfgnn.so -- the C-ABI library of the HIP kernels (include/dfgnn.h).
 
-There is deliberately NO fallback: if the shared library is missing or a symbol is absent this
-module raises, so a GPU box can never silently run a non-HIP path.
+libdfgnn.so is a forwarder without any HIP dependency (csrc/gen_shim.py): it opens the kernels library libdfgnn_hip.so
+next to it at the first call that needs it, so the order in which a process loads this library and torch does not matter.
+There is deliberately NO fallback: if either shared library is missing or a symbol is absent this module (or the first
+operator call) raises, so a GPU box can never silently run a non-HIP path.
 """
 import ctypes
 import os
@@ -53,7 +55,7 @@ def source_hash():
     import re
     mk = open(os.path.join(CSRC, "Makefile")).read()
     names = []
-    for var in ("SRCS", "HDRS"):
+    for var in ("SRCS", "HDRS", "EXTRA"):
         names += re.search(rf"^{var}\s*:=\s*(.*)$", mk, flags=re.M).group(1).split()
     h = hashlib.sha256()
     for n in names + ["Makefile"]:
@@ -62,11 +64,9 @@ def source_hash():
 
 
 def build_id(path=LIB_PATH):
-    """dfgnn_build_id() of a built library (no GPU call).  torch is imported first, as in lib(): the HIP runtime that is
-    loaded first is the one the process uses, and a libdfgnn.so opened ahead of torch brings /opt/rocm's -- a later
-    operator call in the same process (build() followed by smoke()) then hands torch's device pointers to the other
-    runtime and fails with 'bad argument'."""
-    import torch  # noqa: F401
+    """dfgnn_build_id() of a built library: answered by the forwarder itself, no HIP runtime is loaded (round 2 had to
+    import torch first here: the library then linked libamdhip64 and, opened ahead of torch, brought /opt/rocm's runtime
+    into the process next to torch's own)."""
     L = ctypes.CDLL(path)
     L.dfgnn_build_id.restype = ctypes.c_char_p
     return L.dfgnn_build_id().decode()
@@ -91,11 +91,8 @@ def lib():
             raise RuntimeError(
                 f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950). There is no CPU fallback for the fused kernels.")
-        # torch first: it brings its own HIP runtime (libamdhip64 under torch/lib), and the one that is loaded first is
-        # the one the process uses.  Loaded the other way round, libdfgnn.so pulls in /opt/rocm's runtime and torch
-        # then fails to see the GPU ("No HIP GPUs are available") -- the library itself has no torch dependency, this
-        # only fixes the load order inside a torch process.
-        import torch  # noqa: F401
+        # (no import order to respect: libdfgnn.so has no HIP dependency, libdfgnn_hip.so is opened by it at the first
+        # call that needs the kernels -- csrc/gen_shim.py)
         L = ctypes.CDLL(LIB_PATH)
         for name, argtypes in SIGNATURES.items():
             fn = getattr(L, name)  # AttributeError if the library is stale
@@ -118,19 +115,26 @@ def lib():
 def ext():
     """The torch C++ extension (csrc/torch_ext.cpp -> _dfgnn_ext.so, built in-tree by build()): the reference-style
     pybind11 binding over the same C ABI, ~5 us of host time per operator call instead of ~25-60 for ctypes.  None when
-    it is absent, does not belong to this library build, or DFGNN_BINDING=ctypes asks for the ctypes path (tests)."""
+    it is absent, fails to import, was compiled for another library build (its baked-in ABI number and source hash are
+    compared with the library's), or DFGNN_BINDING=ctypes asks for the ctypes path (tests)."""
     global _ext
     if _ext is False:
         _ext = None
         if os.environ.get("DFGNN_BINDING", "ext") != "ctypes" and os.path.exists(EXT_PATH) and \
                 os.path.basename(LIB_PATH) == "libdfgnn.so":
             import importlib.util
-            L = lib()  # libdfgnn.so first (and torch before it): the extension resolves its dfgnn_* symbols against it
-            spec = importlib.util.spec_from_file_location("_dfgnn_ext", EXT_PATH)
-            mod = importlib.util.module_from_spec(spec)
-            spec.loader.exec_module(mod)
-            if mod.abi_version() == L.dfgnn_abi_version() and mod.build_id() == L.dfgnn_build_id().decode():
-                _ext = mod
+            L = lib()  # libdfgnn.so first: the extension resolves its dfgnn_* symbols against it
+            try:
+                import torch  # noqa: F401  (the extension links libtorch)
+                spec = importlib.util.spec_from_file_location("_dfgnn_ext", EXT_PATH)
+                mod = importlib.util.module_from_spec(spec)
+                spec.loader.exec_module(mod)
+                # the extension's OWN compile-time constants against the library's: an extension left over from another
+                # build (or built against another torch: ImportError) is not used, the ctypes path serves instead
+                if mod.abi_version() == L.dfgnn_abi_version() and mod.build_id() == L.dfgnn_build_id().decode():
+                    _ext = mod
+            except (ImportError, OSError, AttributeError):
+                _ext = None
     return _ext
 
 

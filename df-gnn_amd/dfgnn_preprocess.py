@@ -16,6 +16,9 @@ def coo_to_hyper(src, dst, num_nodes, csc=True):
 
     src / dst: int64 or int32 CUDA tensors of equal length (row = src, column = dst).  Stable: the CSR keeps the COO
     order inside a row, the CSC keeps the CSR order inside a column -- the same arrays as the torch path."""
+    ext = _n.ext()
+    if ext is not None and hasattr(ext, "preprocess_hyper") and src.is_cuda and dst.is_cuda:
+        return tuple(ext.preprocess_hyper(src, dst, int(num_nodes), bool(csc)))
     check_device(src=src, dst=dst)
     if src.dtype != dst.dtype or src.dtype not in (torch.int64, torch.int32):
         raise RuntimeError(f"src / dst must both be int64 or int32, got {src.dtype} / {dst.dtype}")

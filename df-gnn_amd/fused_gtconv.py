@@ -199,8 +199,19 @@ def gt_backward_stats(row_ptr, col_ind, Q, K, V, row_max, row_sum, grad):
     return [dQ, dK, dV]
 
 
+def _ext_variant(which, indptr, indices, rows, val, Q, K, V):
+    """The CSR-taking inference variants through the torch C++ binding (csrc/torch_ext.cpp: gt_variant_fwd), or None."""
+    ext = _n.ext()
+    if ext is None or not hasattr(ext, "gt_variant_fwd"):
+        return None
+    return ext.gt_variant_fwd(which, indptr, indices, rows, val, Q, K, V, val_ptr(val) is None)
+
+
 def gt_tiling_inference(indptr, indices, val, smem_consume, Q, K, V):
     """fused_gtconv.cpp:244-276 -> [out]"""
+    out = _ext_variant(0, indptr, indices, None, val, Q, K, V)
+    if out is not None:
+        return [out]
     check_device(indptr=indptr, indices=indices, val=val)
     check_contiguous(indptr=indptr, indices=indices, val=val)
     check_dtype(torch.int32, indptr=indptr, indices=indices)
@@ -217,6 +228,9 @@ def gt_tiling_inference(indptr, indices, val, smem_consume, Q, K, V):
 
 
 def _gt_csr(fn_name, what, indptr, indices, val, Q, K, V):
+    out = _ext_variant(1 if fn_name == "dfgnn_gt_csr_fwd" else 2, indptr, indices, None, val, Q, K, V)
+    if out is not None:
+        return [out]
     check_device(indptr=indptr, indices=indices, val=val)
     check_contiguous(indptr=indptr, indices=indices, val=val)
     check_dtype(torch.int32, indptr=indptr, indices=indices)
@@ -246,6 +260,9 @@ def gt_csr_gm_inference(indptr, indices, val, Q, K, V):
 
 
 def _gt_softmax(fn_name, what, indptr, indices, rows, val, Q, K, V):
+    out = _ext_variant(3 if fn_name == "dfgnn_gt_softmax_fwd" else 4, indptr, indices, rows, val, Q, K, V)
+    if out is not None:
+        return out
     check_device(indptr=indptr, indices=indices, rows=rows, val=val)
     check_contiguous(indptr=indptr, indices=indices, rows=rows, val=val)
     check_dtype(torch.int32, indptr=indptr, indices=indices, rows=rows)

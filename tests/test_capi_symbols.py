@@ -100,12 +100,35 @@ def test_graft_entry_build_passes():
     g.build()
 
 
-def test_nothing_opens_the_library_ahead_of_torch():
-    """The HIP runtime that is loaded first is the one a process uses: libdfgnn.so opened before `import torch` brings
-    /opt/rocm's, and operator calls later in that process then fail with 'bad argument' on torch's device pointers (seen:
-    build() followed by smoke() in one process on the GPU box).  Every loader path -- lib(), build_id(), ext() -- must have
-    torch in the process first."""
+def test_library_opened_ahead_of_torch_brings_no_hip_runtime():
+    """libdfgnn.so is a forwarder (csrc/gen_shim.py): opening it, asking for its ABI number, its build id or the text of an
+    argument error loads neither torch nor a HIP runtime, so a host may link or open it in any order relative to torch (a
+    library that itself linked libamdhip64 brought /opt/rocm's runtime in ahead of torch's own: round 2's 'bad argument'
+    on every torch device pointer).  The kernels library libdfgnn_hip.so is opened at the first call that needs it; the
+    GPU suite runs an operator in a process that opened libdfgnn.so BEFORE importing torch."""
     import subprocess
-    code = ("import sys; sys.path.insert(0, %r); import dfgnn_native as n; assert 'torch' not in sys.modules; "
-            "n.build_id(); assert 'torch' in sys.modules") % os.path.join(ROOT, "df-gnn_amd")
+    code = ("import sys, ctypes; sys.path.insert(0, %r); import dfgnn_native as n; "
+            "L = ctypes.CDLL(n.LIB_PATH); L.dfgnn_build_id.restype = ctypes.c_char_p; "
+            "L.dfgnn_error_string.restype = ctypes.c_char_p; L.dfgnn_error_string.argtypes = [ctypes.c_int]; "
+            "assert L.dfgnn_abi_version() == 9 and L.dfgnn_build_id().decode() == n.source_hash() == n.build_id(); "
+            "assert b'bad argument' in L.dfgnn_error_string(-1); "
+            "maps = open('/proc/self/maps').read(); "
+            "assert 'torch' not in sys.modules and 'libamdhip64' not in maps and 'libdfgnn_hip' not in maps, maps[-3000:]; "
+            "n.lib().dfgnn_plan_ints(10, 40); assert 'libdfgnn_hip.so' in open('/proc/self/maps').read()"
+            ) % os.path.join(ROOT, "df-gnn_amd")
     subprocess.run([sys.executable, "-c", code], check=True, timeout=300)
+
+
+def test_forwarder_has_no_hip_dependency_and_covers_the_header():
+    """readelf / nm on the two libraries: libdfgnn.so needs no HIP library and exports every symbol of include/dfgnn.h;
+    libdfgnn_hip.so exports them too (it is what the forwarder resolves them in)."""
+    import subprocess
+    import dfgnn_native
+    hip = os.path.join(os.path.dirname(dfgnn_native.LIB_PATH), "libdfgnn_hip.so")
+    needed = subprocess.run(["readelf", "-d", dfgnn_native.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    assert "amdhip" not in needed and "hsa" not in needed and "RUNPATH" not in needed and "RPATH" not in needed, needed
+    for path in (dfgnn_native.LIB_PATH, hip):
+        out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+        exported = {ln.split()[-1] for ln in out.splitlines()}
+        missing = [n for n in _declared() if n not in exported]
+        assert not missing, (path, missing)

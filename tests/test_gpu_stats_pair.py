@@ -291,3 +291,41 @@ def test_stats_kernels_write_nothing_outside_their_outputs(heads):
                                       P(bufs["sm"][1]), P(bufs["out"][1]), None, None, s) == -2
     assert L.dfgnn_gt_bwd_stats(m, nnz, heads, f, P(row_ptr), P(col_ind), P(Q), P(K), P(V), None, P(bufs["sm"][1]),
                                 P(dO), P(bufs["dQ"][1]), P(bufs["dK"][1]), P(bufs["dV"][1]), plan, meta, s) == -1
+
+
+def test_operator_runs_in_a_process_that_opened_the_library_before_torch(tmp_path):
+    """The C-ABI library opened FIRST, torch imported afterwards, then an operator: one HIP runtime in the process and a
+    correct result (csrc/gen_shim.py; round 2: 'invalid argument' on torch's device pointers in exactly this order)."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    code = """
+import ctypes, os, sys
+sys.path[:0] = [%(root)r, os.path.join(%(root)r, 'df-gnn_amd'), os.path.join(%(root)r, 'tests')]
+lib = ctypes.CDLL(os.path.join(%(root)r, 'df-gnn_amd', 'libdfgnn.so'))      # before torch
+assert lib.dfgnn_abi_version() == 9 and 'torch' not in sys.modules
+import numpy as np, torch
+import oracle
+from DFGNN.layers import preprocess_Hyper_fw_bw
+from DFGNN.operators.fused_gtconv import GTConvFuse_hyper
+from DFGNN.utils import synthetic as S
+g = S.pattern_like(batch_size=6, seed=2).to('cuda:0')
+A, rows, row_ptr, col_ind, val, col_ptr, row_ind, val_idx, smem = preprocess_Hyper_fw_bw(g)
+m = g.num_nodes()
+Q, K, V = (t.requires_grad_(True) for t in S.gt_features(m, 1, 128, seed=1, device='cuda:0'))
+dO = torch.randn(m, 1, 128, device='cuda:0')
+out = GTConvFuse_hyper(rows, row_ptr, col_ind, val, col_ptr, row_ind, val_idx, smem, Q, K, V)
+out.backward(dO)
+n = lambda t: t.detach().cpu().numpy()
+want = oracle.gt_forward(n(row_ptr), n(col_ind), n(val), n(Q), n(K), n(V))
+wq, wk, wv = oracle.gt_backward(n(row_ptr), n(col_ind), n(val), n(Q), n(K), n(V), n(dO))
+for got, ref in ((out, want), (Q.grad, wq), (K.grad, wk), (V.grad, wv)):
+    assert np.abs(n(got).astype(np.float64) - ref).max() < 1e-3
+maps = open('/proc/self/maps').read()
+hip = sorted({ln.split()[-1] for ln in maps.splitlines() if 'libamdhip64' in ln})
+assert len(hip) == 1, hip                                                      # ONE HIP runtime: torch's
+assert 'libdfgnn_hip.so' in maps
+print('ok', hip[0])
+""" % {"root": ROOT}
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stdout[-1500:] + out.stderr[-3000:]
