@@ -37,6 +37,7 @@ SIGNATURES = {
     "dfgnn_gat_softmax_fwd": [_i, _i, _i, _i] + [_vp] * 5 + [_f] + [_vp] * 4,
     "dfgnn_gat_softmax_gm_fwd": [_i, _i, _i, _i] + [_vp] * 5 + [_f] + [_vp] * 4,
     "dfgnn_gat_tiling_fwd": [_i, _i, _i, _i] + [_vp] * 4 + [_f] + [_vp] * 3,
+    "dfgnn_gat_tiling_chunked_fwd": [_i, _i, _i, _i, _i] + [_vp] * 4 + [_f] + [_vp] * 3 + [ctypes.c_size_t, _vp],
     "dfgnn_gat_attn_scores": [_i, _i, _i] + [_vp] * 6,
     "dfgnn_gat_fwd_train": [_i, _i, _i, _i] + [_vp] * 5 + [_f] + [_vp] * 2 + [_f] + [_vp] * 6,
     "dfgnn_gat_bwd": [_i, _i, _i, _i] + [_vp] * 8 + [_f] + [_vp] * 4 + [_f] + [_vp] * 8,
@@ -108,6 +109,8 @@ def lib():
         L.dfgnn_plan_applies.restype = ctypes.c_int
         L.dfgnn_preprocess_ws_bytes.argtypes = [ctypes.c_int, ctypes.c_int]
         L.dfgnn_preprocess_ws_bytes.restype = ctypes.c_size_t
+        L.dfgnn_gat_tiling_chunked_ws_bytes.argtypes = [ctypes.c_int] * 4
+        L.dfgnn_gat_tiling_chunked_ws_bytes.restype = ctypes.c_size_t
         _lib = L
     return _lib
 

@@ -11,7 +11,8 @@ tensors from the training forward; its schedule argument only distributes work a
 import torch
 
 import dfgnn_native as _n
-from _binding_util import as_int32, check_contiguous, check_device, check_dtype, get_plan, get_rows, ptr, stream_ptr
+from _binding_util import (_KeyedCache, as_int32, check_contiguous, check_device, check_dtype, get_plan, get_rows, ptr,
+                           stream_ptr)
 
 # Set to False to force the general (plan-less) kernels; results are identical either way.
 USE_BLOCK_PLAN = True
@@ -92,8 +93,66 @@ def gat_inference_softmax_gm(attn_row, attn_col, indptr, indices, rows, negative
                     rows, negative_slope, in_feat)
 
 
+# ---- 'tiling' on super-node full graphs: column chunks that fit an XCD's L2 (csrc/gat_tiling_chunked.hip) -----------------
+# The chunk-major edge order of a graph is preprocessing, like the block plan of a batch: built on first use, cached by
+# the identity of the CSR arrays' memory.  TILING_CHUNK_ROWS = 0 keeps the single-kernel form everywhere.
+# Rows of a chunk: TILING_CHUNK_BYTES / (4 f), a multiple of 1024, at most 32768 (16-bit column offsets).  6 MiB per chunk
+# measured best on the reddit-like graph at f = 128 (12288 rows: 4.28 ms; 8192 rows = one XCD's 4 MiB L2: 4.89 ms -- more
+# chunks, more partial states; 16384 rows: 4.74 ms; the single-kernel form: 8.27 ms).  0 = the single-kernel form everywhere.
+TILING_CHUNK_BYTES = 6 << 20
+TILING_CHUNK_ROWS = None           # tests: a fixed number of rows per chunk instead
+TILING_CHUNK_MIN_TABLE = 64 << 20  # feature table (bytes) below which the L2s hold it anyway
+TILING_CHUNK_MIN_DEGREE = 64       # average degree below which a row of X is not re-used enough to pay for the partial states
+_chunk_cache = _KeyedCache(entries=4)
+
+
+def _tiling_chunks(row_ptr, col_ind, chunk_rows):
+    """(seg_ptr int32[nchunks m + 1], ccol int16[nnz]) of include/dfgnn.h: dfgnn_gat_tiling_chunked_fwd."""
+    key = _KeyedCache.key_of(row_ptr, col_ind, extra=(chunk_rows,))
+    hit = _chunk_cache.get(key)
+    if hit is None:
+        m, nnz = row_ptr.size(0) - 1, col_ind.size(0)
+        nchunks = (m + chunk_rows - 1) // chunk_rows
+        with torch.cuda.device(col_ind.device):
+            chunk = torch.div(col_ind, chunk_rows, rounding_mode="floor").to(torch.int16)
+            order = torch.sort(chunk, stable=True).indices           # CSR (row-major) order survives inside a chunk
+            ccol = (col_ind - chunk.to(torch.int32) * chunk_rows).to(torch.int16)[order].contiguous()
+            rows = get_rows(row_ptr, nnz)
+            counts = torch.bincount(chunk.long() * m + rows.long(), minlength=nchunks * m)
+            seg_ptr = torch.zeros(nchunks * m + 1, dtype=torch.int32, device=col_ind.device)
+            seg_ptr[1:] = torch.cumsum(counts, 0).to(torch.int32)
+            del chunk, order, counts
+        hit = _chunk_cache.put(key, (seg_ptr, ccol), row_ptr, col_ind)
+    return hit
+
+
+def _chunk_rows(f):
+    if TILING_CHUNK_ROWS is not None:
+        return int(TILING_CHUNK_ROWS)
+    return min(32768, (TILING_CHUNK_BYTES // (4 * f)) // 1024 * 1024)
+
+
+def _use_chunked_tiling(m, nnz, h, f):
+    return (_chunk_rows(f) > 0 and m * h * f * 4 >= TILING_CHUNK_MIN_TABLE and nnz >= TILING_CHUNK_MIN_DEGREE * m and
+            nnz < 2 ** 31)
+
+
 def gat_inference_tiling(attn_row, attn_col, row_ptr, col_ind, negative_slope, in_feat):
     """fused_gatconv.cpp:196-219 -> Tensor"""
+    if in_feat.dim() == 3 and in_feat.is_cuda and row_ptr.dim() == 1 and col_ind.dim() == 1 and \
+            _use_chunked_tiling(row_ptr.size(0) - 1, col_ind.size(0), in_feat.size(1), in_feat.size(2)):
+        m, nnz, h, f = _check(attn_row, attn_col, row_ptr, col_ind, None, in_feat)
+        chunk_rows = _chunk_rows(f)
+        seg_ptr, ccol = _tiling_chunks(row_ptr, col_ind, chunk_rows)
+        L = _n.lib()
+        with torch.cuda.device(in_feat.device):
+            out = torch.empty_like(in_feat)
+            ws_bytes = int(L.dfgnn_gat_tiling_chunked_ws_bytes(m, h, f, chunk_rows))
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=in_feat.device)
+            _n.check(L.dfgnn_gat_tiling_chunked_fwd(m, nnz, h, f, chunk_rows, ptr(seg_ptr), ptr(ccol), ptr(attn_row),
+                                                    ptr(attn_col), float(negative_slope), ptr(in_feat), ptr(out), ptr(ws),
+                                                    ws_bytes, stream_ptr(in_feat.device)), "gat_inference_tiling (chunked)")
+        return out
     ext = _n.ext()
     if ext is not None:
         return ext.gat_tiling_fwd(attn_row, attn_col, row_ptr, col_ind, float(negative_slope), in_feat)

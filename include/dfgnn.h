@@ -217,6 +217,21 @@ int dfgnn_gat_tiling_fwd(int m, int nnz, int h, int f, const int *row_ptr, const
                          const float *attn_row, const float *attn_col, float negative_slope,
                          const float *X, float *out, dfgnn_stream_t stream);
 
+/* dfgnn_gat_tiling_fwd for super-node full graphs whose feature table [m, h, f] does not fit the L2s (reddit: 119 MB): the
+ * columns are cut into chunks of `chunk_rows` nodes (<= 32768; 8192 x 512 B = one XCD's 4 MiB L2), the edges are
+ * re-ordered chunk-major, every (row, chunk) segment gives an online-softmax partial state and a second kernel merges
+ * a row's states (csrc/gat_tiling_chunked.hip).  Same result as dfgnn_gat_tiling_fwd to fp32 rounding.
+ *   seg_ptr  int32[nchunks * m + 1], nchunks = ceil(m / chunk_rows): the edges of row r into chunk c are
+ *            seg_ptr[c m + r] .. seg_ptr[c m + r + 1] of the chunk-major edge order (= the CSR order sorted stably by
+ *            the chunk of the column)
+ *   ccol     int16[nnz]: column - chunk * chunk_rows of every edge in that order
+ *   ws       device workspace of dfgnn_gat_tiling_chunked_ws_bytes(m, h, f, chunk_rows) bytes (partial states)
+ * seg_ptr / ccol depend on the graph only: preprocessing, built once (the Python binding builds and caches them). */
+size_t dfgnn_gat_tiling_chunked_ws_bytes(int m, int h, int f, int chunk_rows);
+int dfgnn_gat_tiling_chunked_fwd(int m, int nnz, int h, int f, int chunk_rows, const int *seg_ptr, const short *ccol,
+                                 const float *attn_row, const float *attn_col, float negative_slope, const float *X,
+                                 float *out, void *ws, size_t ws_bytes, dfgnn_stream_t stream);
+
 /* First kernel of the reference's 'hyper_v2' variant (gat_inference_hyper_v2, fused_gatconv.cpp:148-158;
  * fused_gat_dot_attn_weight, fused_gatconv_hyper_v2.cu:212-249): the per-node attention scores from the layer's
  * attention vectors a_l, a_r fp32[h, f]:  attn_row[i, hd] = <a_l[hd], X[i, hd]>,  attn_col[i, hd] = <a_r[hd], X[i, hd]>.

@@ -26,7 +26,8 @@ def test_header_symbols_exported():
 def test_loader_signatures_cover_header():
     import dfgnn_native
     compute = [n for n in _declared() if n not in ("dfgnn_abi_version", "dfgnn_error_string", "dfgnn_build_id",
-                                                       "dfgnn_plan_ints", "dfgnn_plan_applies", "dfgnn_preprocess_ws_bytes")]
+                                                       "dfgnn_plan_ints", "dfgnn_plan_applies", "dfgnn_preprocess_ws_bytes",
+                                                       "dfgnn_gat_tiling_chunked_ws_bytes")]
     assert sorted(dfgnn_native.SIGNATURES) == compute
     lib = dfgnn_native.lib()
     assert lib.dfgnn_abi_version() == 9

@@ -323,6 +323,22 @@ def test_c4_reddit_like_full_size_spot_rows():
         assert (err <= ATOL + RTOL * np.abs(ref)).all(), f"row {r} (degree {int(deg[r])}): max abs err {err.max():.3e}"
         worst = max(worst, float(err.max()))
     assert int(deg.max()) > 15000 and worst < 1e-4
+    # every row of the output against the oracle's fp32 build on the host cores (a pass over 114.6 M edges: seconds), and
+    # the chunked form (what the operator runs at this size: fused_gatconv._use_chunked_tiling) against the single kernel
+    import fused_gatconv as gat
+    import oracle
+    assert gat._use_chunked_tiling(m, nnz, 1, 128)
+    full = oracle.gat_forward(row_ptr.cpu().numpy(), col_ind.cpu().numpy(), ar.cpu().numpy(), ac.cpu().numpy(), 0.2,
+                              X.cpu().numpy(), acc="f32")
+    err = np.abs(out.cpu().numpy().astype(np.float64) - full)
+    assert (err <= ATOL + RTOL * np.abs(full)).all(), f"full output: max abs err {err.max():.3e}"
+    rows_tmp = gat.TILING_CHUNK_ROWS
+    try:
+        gat.TILING_CHUNK_ROWS = 0
+        single = ops.GATConvFuse_inference_tiling(ar, ac, row_ptr, col_ind, 0.2, X)
+    finally:
+        gat.TILING_CHUNK_ROWS = rows_tmp
+    assert torch.allclose(out, single, atol=1e-5, rtol=1e-4) and not torch.equal(out, single)   # two code paths did run
     o1 = ops.GATConvFuse_inference_tiling(ar, ac, row_ptr, col_ind, 0.2, torch.ones_like(X))
     nonempty = (deg > 0).to(DEV)
     assert torch.allclose(o1[nonempty], torch.ones_like(o1[nonempty]), atol=1e-4) and bool((o1[~nonempty] == 0).all())
