@@ -32,9 +32,9 @@ class FusedGTFunction_hyper(torch.autograd.Function):
     @staticmethod
     def forward(ctx, rows, row_ptr, col_ind, val, col_ptr, row_ind, val_idx, smem_consume, Q, K, V):
         ctx.smem = smem_consume
-        ctx.stats = fused_gt.gt_stats_pair_applies(row_ptr, col_ind, val, Q)
-        if ctx.stats:
-            out_feat, row_max, row_sum = fused_gt.gt_hyper_forward_stats(row_ptr, col_ind, Q, K, V)
+        ctx.stats = fused_gt.gt_stats_pair_applies(row_ptr, col_ind, val, Q)   # the block plan, or None
+        if ctx.stats is not None:
+            out_feat, row_max, row_sum = fused_gt.gt_hyper_forward_stats(row_ptr, col_ind, Q, K, V, ctx.stats)
             ctx.save_for_backward(row_ptr, col_ind, Q, K, V, row_max, row_sum)
             return out_feat
         out_feat, attn_edge = fused_gt.gt_hyper_forward(
@@ -44,10 +44,10 @@ class FusedGTFunction_hyper(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_out):
-        if ctx.stats:
+        if ctx.stats is not None:
             row_ptr, col_ind, Q, K, V, row_max, row_sum = ctx.saved_tensors
             grad_Q, grad_K, grad_V = fused_gt.gt_backward_stats(row_ptr, col_ind, Q, K, V, row_max, row_sum,
-                                                                grad_out.contiguous())
+                                                                grad_out.contiguous(), ctx.stats)
             return (None,) * 8 + (grad_Q, grad_K, grad_V)
         row_ptr, col_ind, rows, val, col_ptr, row_ind, val_idx, Q, K, V, attn_edge = ctx.saved_tensors
         grad_Q, grad_K, grad_V = fused_gt.gt_backward(

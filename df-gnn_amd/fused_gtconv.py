@@ -144,18 +144,28 @@ USE_STATS_PAIR = os.environ.get("DFGNN_STATS", "1") != "0"
 
 
 def gt_stats_pair_applies(row_ptr, col_ind, val, Q):
-    """True when gt_hyper_forward_stats / gt_backward_stats can serve this call: unit edge values and a block plan whose
-    ranges are all dense (dfgnn_gt_stats_applies)."""
+    """The block plan (a true value) when gt_hyper_forward_stats / gt_backward_stats can serve this call -- unit edge
+    values and a plan whose ranges are all dense (dfgnn_gt_stats_applies) -- else None.  The plan may be handed to the two
+    calls (`plan=`), which then skip their own look-up."""
     if not (USE_STATS_PAIR and USE_BLOCK_PLAN) or Q.dim() != 3 or not Q.is_cuda:
-        return False
+        return None
     plan = get_plan_obj(row_ptr, col_ind, Q.size(-1), True)
-    return plan is not None and plan.stats_applies(Q.size(1)) and val_ptr(val) is None
+    if plan is not None and plan.stats_applies(Q.size(1)) and val_ptr(val) is None:
+        return plan
+    return None
 
 
-def gt_hyper_forward_stats(row_ptr, col_ind, Q, K, V):
+def _plan_ptrs(plan, row_ptr, col_ind, Q):
+    if plan is not None:
+        return plan.ptrs()
+    p, m, _ = get_plan(row_ptr, col_ind, Q.size(-1) if Q.dim() == 3 else 0, USE_BLOCK_PLAN)
+    return p, m
+
+
+def gt_hyper_forward_stats(row_ptr, col_ind, Q, K, V, plan=None):
     """-> [out, row_max[m, h], row_sum[m, h]]: the training forward without attn_edge (call gt_stats_pair_applies first)."""
     ext = _n.ext()
-    plan, meta, _ = get_plan(row_ptr, col_ind, Q.size(-1) if Q.dim() == 3 else 0, USE_BLOCK_PLAN)
+    plan, meta = _plan_ptrs(plan, row_ptr, col_ind, Q)
     if ext is not None and hasattr(ext, "gt_hyper_fwd_stats"):
         return ext.gt_hyper_fwd_stats(row_ptr, col_ind, Q, K, V, plan or 0, meta or 0)
     check_device(row_ptr=row_ptr, col_ind=col_ind)
@@ -174,10 +184,10 @@ def gt_hyper_forward_stats(row_ptr, col_ind, Q, K, V):
     return [out, row_max, row_sum]
 
 
-def gt_backward_stats(row_ptr, col_ind, Q, K, V, row_max, row_sum, grad):
+def gt_backward_stats(row_ptr, col_ind, Q, K, V, row_max, row_sum, grad, plan=None):
     """-> [dQ, dK, dV] from the row statistics of gt_hyper_forward_stats (P is recomputed on the matrix cores)."""
     ext = _n.ext()
-    plan, meta, _ = get_plan(row_ptr, col_ind, Q.size(-1) if Q.dim() == 3 else 0, USE_BLOCK_PLAN)
+    plan, meta = _plan_ptrs(plan, row_ptr, col_ind, Q)
     if ext is not None and hasattr(ext, "gt_bwd_stats"):
         return ext.gt_bwd_stats(row_ptr, col_ind, Q, K, V, row_max, row_sum, grad, plan or 0, meta or 0)
     check_device(row_ptr=row_ptr, col_ind=col_ind, row_max=row_max, row_sum=row_sum, grad=grad)

@@ -61,9 +61,9 @@ if H == 1:
     print("FWD stats (512-thread body)")
     run(lambda: gt.gt_hyper_forward_stats(row_ptr, col_ind, Q, K, V), nd, [0, 1, 2, 3, 4, 5],
         ["prologue+K img", "S", "softmax", "V img", "PV+store"])
-    print("BWD stats (rc body: ranges of <= 128 nodes only are stamped)")
-    run(lambda: gt.gt_backward_stats(row_ptr, col_ind, Q, K, V, mx, sm, dO), nd, [0, 1, 2, 3, 4, 5, 6, 7, 8],
-        ["V img", "dP", "K img", "S,P,dS,dQ,P->tile", "dO img", "dV", "dS->tile,Q img", "dK"])
+    print("BWD stats (rc2 body: ranges of <= 128 nodes only are stamped)")
+    run(lambda: gt.gt_backward_stats(row_ptr, col_ind, Q, K, V, mx, sm, dO), nd, [0, 1, 2, 3, 4, 5, 6, 7],
+        ["[dO|V] img", "dP", "[Q|K] img", "S,P,dS,dQ", "dS->tile,dK", "dO img,P->tile", "dV"])
 else:
     print("BWD stats multi-head (heads2 body)")
     sel = np.arange(nd) * H   # the workgroups of head 0 (stamp row = blockIdx.x * gridDim.y + blockIdx.y)
