@@ -35,29 +35,43 @@ class OverlappedGradSync:
             for p in params:
                 p.register_post_accumulate_grad_hook(self._hook(bucket, off, p.numel()))
                 off += p.numel()
+        self._next = len(self.buckets) - 1      # the bucket whose all-reduce goes out next
+
+    def _issue_ready(self, everything=False):
+        # collectives go out in ONE order on every rank -- last block first, the order the backward fills them in -- and
+        # a bucket waits for the ones after it: ranks that fill different buckets still pair up the same calls
+        while self._next >= 0 and (everything or self.buckets[self._next]["ready"] == len(self.buckets[self._next]["params"])):
+            b = self.buckets[self._next]
+            b["handle"] = dist.all_reduce(b["flat"], group=self.group, async_op=True)
+            self._next -= 1
 
     def _hook(self, bucket, off, n):
         def fn(p):
+            if bucket["handle"] is not None:
+                raise RuntimeError("OverlappedGradSync: a second backward reached bucket '%s' while its all-reduce from "
+                                   "the previous one is still pending -- call finish() after every backward" % bucket["name"])
             bucket["flat"][off:off + n].copy_(p.grad.reshape(-1))
             bucket["ready"] += 1
-            if self.overlap and bucket["ready"] == len(bucket["params"]):
-                bucket["handle"] = dist.all_reduce(bucket["flat"], group=self.group, async_op=True)
+            if self.overlap:
+                self._issue_ready()
         return fn
 
     def finish(self):
-        """Wait for every bucket (issue the ones that were not overlapped) and write the summed gradients back."""
+        """Wait for every bucket (issue the ones that were not overlapped) and write the summed gradients back.
+        EVERY bucket is reduced on EVERY rank, in the same order, whether or not a gradient reached it here (its slots
+        are then zeros): ranks whose shards exercise different parameters still issue the same collectives.  A
+        parameter without a local gradient receives the other ranks' sum."""
+        self._issue_ready(everything=True)
+        self._next = len(self.buckets) - 1
         for b in self.buckets:
-            if b["ready"] == 0:
-                continue                        # no gradient reached this block in this backward
-            if b["handle"] is None:
-                b["handle"] = dist.all_reduce(b["flat"], group=self.group, async_op=True)
-        for b in self.buckets:
-            if b["handle"] is None:
-                continue
             b["handle"].wait()
             off = 0
             for p in b["params"]:
+                piece = b["flat"][off:off + p.numel()].view_as(p)
                 if p.grad is not None:
-                    p.grad.copy_(b["flat"][off:off + p.numel()].view_as(p.grad))
+                    p.grad.copy_(piece)
+                else:
+                    p.grad = piece.clone()
                 off += p.numel()
+            b["flat"].zero_()                   # slots no gradient reaches in the next backward travel as zeros
             b["ready"], b["handle"] = 0, None

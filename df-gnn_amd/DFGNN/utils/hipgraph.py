@@ -6,8 +6,7 @@ is capturable (no allocation, no host synchronisation inside, launches on the ca
 step can be recorded once and replayed with a single hipGraphLaunch:
 
     def fwd_bwd():                                        # explicit operator calls (fused_gtconv / fused_gatconv)
-        out, attn = fused_gtconv.gt_hyper_forward(row_ptr, col_ind, rows, val, col_ptr, row_ind, val_idx, smem, Q, K, V)
-        return [out] + fused_gtconv.gt_backward(row_ptr, col_ind, rows, val, col_ptr, row_ind, val_idx, smem, Q, K, V, attn, dO)
+        return fused_gtconv.gt_hyper_step_raw(row_ptr, col_ind, rows, val, col_ptr, row_ind, val_idx, smem, Q, K, V, dO)
     step = GraphedStep(fwd_bwd)                           # warm-up (builds and caches the block plan), then capture
     out, dQ, dK, dV = step.replay()                       # same tensors every time: copy new inputs in place
 

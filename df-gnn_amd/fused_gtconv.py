@@ -162,6 +162,17 @@ def _plan_ptrs(plan, row_ptr, col_ind, Q):
     return p, m
 
 
+def gt_hyper_step_raw(row_ptr, col_ind, rows, val, col_ptr, row_ind, val_idx, smem, Q, K, V, grad):
+    """-> [out, dQ, dK, dV]: the launches of one FusedGTFunction_hyper forward + backward as explicit operator calls (no
+    autograd graph), choosing the pair the way the autograd function does -- what the HIP-graph replays capture."""
+    plan = gt_stats_pair_applies(row_ptr, col_ind, val, Q)
+    if plan is not None:
+        out, rmax, rsum = gt_hyper_forward_stats(row_ptr, col_ind, Q, K, V, plan=plan)
+        return [out] + list(gt_backward_stats(row_ptr, col_ind, Q, K, V, rmax, rsum, grad, plan=plan))
+    out, attn = gt_hyper_forward(row_ptr, col_ind, rows, val, col_ptr, row_ind, val_idx, smem, Q, K, V)
+    return [out] + list(gt_backward(row_ptr, col_ind, rows, val, col_ptr, row_ind, val_idx, smem, Q, K, V, attn, grad))
+
+
 def gt_hyper_forward_stats(row_ptr, col_ind, Q, K, V, plan=None):
     """-> [out, row_max[m, h], row_sum[m, h]]: the training forward without attn_edge (call gt_stats_pair_applies first)."""
     ext = _n.ext()

@@ -141,3 +141,67 @@ def test_overlapped_weight_gradient_exchange_matches_full_batch():
         g_overlap, g_plain = ret[rank]
         assert torch.allclose(g_overlap, g_plain, atol=1e-7)
         assert torch.allclose(g_overlap, want, atol=1e-6, rtol=1e-5)
+
+
+def _partial_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from DFGNN.parallel import OverlappedGradSync
+        torch.manual_seed(0)
+
+        class Two(torch.nn.Module):
+            def __init__(self):
+                super().__init__()
+                self.blk = torch.nn.ModuleDict({"a": torch.nn.Linear(4, 1, bias=False), "b": torch.nn.Linear(4, 1, bias=False)})
+                self.other = torch.nn.Linear(4, 1, bias=False)
+
+        out = {}
+        for overlap in (True, False):
+            model = Two()
+            sync = OverlappedGradSync(model, overlap=overlap)
+            x = torch.arange(4.0)[None] + rank
+            # step 1: every rank uses blk.a; only rank 0 uses blk.b (a bucket that is only partly filled on rank 1) and
+            # only rank 1 uses `other` (a bucket no gradient reaches on rank 0)
+            loss = model.blk["a"](x).sum() + (model.blk["b"](x).sum() if rank == 0 else 0) + (model.other(x).sum() if rank == 1 else 0)
+            loss.backward()
+            sync.finish()
+            g1 = {n: p.grad.clone() for n, p in model.named_parameters()}
+            # step 2 (grads kept, zero_grad(set_to_none=False)): nobody uses blk.b now -- its slot must travel as zeros
+            model.zero_grad(set_to_none=False)
+            (2 * model.blk["a"](x).sum()).backward()
+            sync.finish()
+            g2 = {n: p.grad.clone() for n, p in model.named_parameters()}
+            refused = False
+            if overlap:
+                model.other(x).sum().backward()         # completes the last bucket: its all-reduce is now in flight
+                try:
+                    model.other(x).sum().backward()     # a second backward before finish()
+                except RuntimeError as e:
+                    refused = "finish()" in str(e)
+                sync.finish()
+            out[overlap] = (g1, g2, refused)
+        ret[rank] = out
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(240)
+def test_gradient_exchange_with_buckets_only_some_ranks_fill():
+    """OverlappedGradSync when a bucket gets gradients for only some of its parameters, or none at all, on some rank:
+    every rank still issues the same collectives (no hang), missing slots travel as zeros (not as the previous step's
+    values), and a second backward while a bucket's all-reduce is pending is refused."""
+    world = 2
+    ret = mp.get_context("spawn").Manager().dict()
+    mp.spawn(_partial_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    x0, x1 = torch.arange(4.0)[None], torch.arange(4.0)[None] + 1
+    for rank in range(world):
+        for overlap in (True, False):
+            g1, g2, refused = ret[rank][overlap]
+            assert torch.equal(g1["blk.a.weight"], x0 + x1)
+            assert torch.equal(g1["blk.b.weight"], x0)            # rank 1 contributed zeros
+            assert torch.equal(g1["other.weight"], x1)            # rank 0 had no gradient at all: it receives rank 1's
+            assert torch.equal(g2["blk.a.weight"], 2 * (x0 + x1))
+            assert torch.equal(g2["blk.b.weight"], torch.zeros(1, 4))   # not step 1's slot again
+            assert torch.equal(g2["other.weight"], torch.zeros(1, 4))
+            assert refused == overlap

@@ -208,8 +208,9 @@ def test_check_correct_follows_the_reference_rule(capsys):
 
 def test_dotgat_baseline_restates_dgl_dotgatconv():
     """DotGatConv (the torch restatement of dgl.nn.DotGatConv behind the DOTGAT layers' non-fused branch) against a
-    per-node loop of the published algorithm: e_uv = <h_u, h_v>, softmax over the edges arriving at v, sum of a_uv h_u;
-    on a symmetric graph it equals the GT oracle with Q = K = V = H (what the fused branch computes)."""
+    per-node loop of the published algorithm: e_uv = <h_u, h_v> / sqrt(out_feats), softmax over the edges arriving at v,
+    sum of a_uv h_u; on a symmetric graph it equals the GT oracle with Q = H / sqrt(out_feats), K = V = H (what the fused
+    branch computes).  dgl itself is absent: parity with the module it restates is unpinned."""
     import oracle
     from DFGNN.layers.GAT_DOT import DotGatConv
     from DFGNN.layers.util import preprocess_CSR
@@ -228,13 +229,13 @@ def test_dotgat_baseline_restates_dgl_dotgatconv():
         if len(us) == 0:
             continue
         for hd in range(2):
-            e = (h[us, hd] * h[v, hd]).sum(-1)
+            e = (h[us, hd] * h[v, hd]).sum(-1) / 5 ** 0.5
             a = torch.softmax(e, 0)
             want[v, hd] = (a[:, None] * h[us, hd]).sum(0)
     assert torch.allclose(out, want, atol=1e-5)
     row_ptr, col_ind, val, _ = preprocess_CSR(g)
     hn = h.numpy()
-    ref = oracle.gt_forward(row_ptr.numpy(), col_ind.numpy(), val.numpy(), hn, hn, hn)
+    ref = oracle.gt_forward(row_ptr.numpy(), col_ind.numpy(), val.numpy(), (hn / np.float32(5 ** 0.5)), hn, hn)
     assert np.abs(out.numpy() - ref).max() < 1e-5
 
 

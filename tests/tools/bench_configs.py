@@ -154,8 +154,7 @@ if "c5" in args:
         def raw_step(gargs=gargs, Q=Q, K=K, V=V, dO=dO):   # the same launches as explicit operator calls ...
             rows_, row_ptr_, rest = gargs[0], gargs[1], gargs[2:]
             with torch.no_grad():
-                o, attn = _gtb.gt_hyper_forward(row_ptr_, rest[0], rows_, *rest[1:], Q, K, V)
-                return [o] + _gtb.gt_backward(row_ptr_, rest[0], rows_, *rest[1:], Q, K, V, attn, dO)
+                return _gtb.gt_hyper_step_raw(row_ptr_, rest[0], rows_, *rest[1:], Q, K, V, dO)
 
         # (every eager run before the first capture: a captured graph keeps its memory pool.)  The reference's protocol
         # (3 + 10 calls) five times over, median: one host hiccup inside a 10-call window -- an allocator miss, the

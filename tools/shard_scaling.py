@@ -40,10 +40,8 @@ def main():
 
             def raw_step(W=W):
                 with torch.no_grad():
-                    o, at = fused_gtconv.gt_hyper_forward(W.row_ptr, W.col_ind, W.rows, W.val, W.col_ptr, W.row_ind,
-                                                          W.val_idx, W.smem, W.Q, W.K, W.V)
-                    return fused_gtconv.gt_backward(W.row_ptr, W.col_ind, W.rows, W.val, W.col_ptr, W.row_ind,
-                                                    W.val_idx, W.smem, W.Q, W.K, W.V, at, W.dO)
+                    return fused_gtconv.gt_hyper_step_raw(W.row_ptr, W.col_ind, W.rows, W.val, W.col_ptr, W.row_ind,
+                                                          W.val_idx, W.smem, W.Q, W.K, W.V, W.dO)[1:]
 
             eager.append(bench.wall_ms(W.step, reps=args.steps, warm=5))
             graph.append(bench.wall_ms(GraphedStep(raw_step).replay, reps=args.steps, warm=5))

@@ -53,6 +53,7 @@ def run(args, fuse, dev, overlap=None):
         from DFGNN.parallel import OverlappedGradSync, shard_graph
         sync = OverlappedGradSync(model, overlap=bool(overlap))
     graphs = [S.pattern_like(batch_size=args.batch_size, seed=10 + b) for b in range(args.batches)]
+    global_nodes = [g.num_nodes() for g in graphs]  # squared errors / nodes of the WHOLE batch: shard gradients sum to its mean-loss gradient
     if world > 1:
         graphs = [shard_graph(g, rank, world)[0] for g in graphs]
     graphs = [g.to(dev) for g in graphs]
@@ -72,7 +73,7 @@ def run(args, fuse, dev, overlap=None):
             params = (params[0],) + (None,) * 8
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        loss = nn.functional.mse_loss(model(params, feats[b], fuse), target[b])
+        loss = nn.functional.mse_loss(model(params, feats[b], fuse), target[b], reduction="sum") / global_nodes[b]
         torch.cuda.synchronize()
         t2 = time.perf_counter()
         opt.zero_grad(set_to_none=True)
