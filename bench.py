@@ -4,10 +4,12 @@ batch bs=1024, dim=128, heads=1 (BASELINE.json configs[2]), on N GPUs of one nod
 
 One "step" = one pass of the hot path over one resident batch: GTConvFuse_hyper forward + its autograd backward
 (dQ, dK, dV) at the operator boundary, exactly what DFGNN/script/train/train_batch_graph_timing.py times per layer in
-the reference.  On this batch (every member graph a dense range of the block plan, unit edge values)
-FusedGTFunction_hyper takes the statistics-saving pair: the forward writes out + two floats per (row, head) instead of
-attn_edge, the backward recomputes the attention (include/dfgnn.h: dfgnn_gt_hyper_fwd_stats / dfgnn_gt_bwd_stats); the
-attn_edge pair (the reference's form) is timed next to it as `secondary.attn_edge_pair`.
+the reference.  FusedGTFunction_hyper has two forms of the pair on a batch like this one (every
+member graph a dense range of the block plan, unit edge values): the reference's -- the forward writes attn_edge, the
+backward reads it -- and one that saves two floats per (row, head) and recomputes the attention in the backward
+(include/dfgnn.h: dfgnn_gt_hyper_fwd_stats / dfgnn_gt_bwd_stats).  It takes the faster one: the attn_edge pair at one
+head (this headline), the statistics pair from two heads on (--heads 2/4/8).  Both are timed; the one the step does not
+launch is reported under `secondary` (`row_statistics_pair` / `attn_edge_pair`).
 Inputs (CSR/COO/CSC index arrays, Q, K, V, dO) are resident in HBM before the timed region.
 
 N > 1: one process per GPU (torch.distributed, RCCL).  Launched by the driver as `python -m torch.distributed.run
@@ -326,16 +328,17 @@ def main():
     plan, plan_meta, _ = get_plan(W.row_ptr, W.col_ind, f, fused_gtconv.USE_BLOCK_PLAN)
     VP = val_ptr(W.val)  # NULL for unit edge values, exactly as the binding passes it (fused_gtconv.py)
 
-    uses_stats = fused_gtconv.gt_stats_pair_applies(W.row_ptr, W.col_ind, W.val, W.Q)  # what the timed step launches
+    uses_stats = fused_gtconv.gt_stats_pair_chosen(W.row_ptr, W.col_ind, W.val, W.Q)  # what the timed step launches
+    stats_can = fused_gtconv.gt_stats_pair_applies(W.row_ptr, W.col_ind, W.val, W.Q)  # ... and whether the other pair could run
     with torch.no_grad():
         rmax, rsum = torch.empty(m, h, device=dev), torch.empty(m, h, device=dev)
 
     def fwd_stats_call():
-        return L.dfgnn_gt_hyper_fwd_stats(m, nnz, h, f, P(W.row_ptr), P(W.col_ind), P(W.Q), P(W.K), P(W.V), P(rmax), P(rsum),
+        return L.dfgnn_gt_hyper_fwd_stats(m, nnz, h, f, P(W.row_ptr), P(W.col_ind), None, P(W.Q), P(W.K), P(W.V), P(rmax), P(rsum),
                                           P(out), plan, plan_meta, stream)
 
     def bwd_stats_call():
-        return L.dfgnn_gt_bwd_stats(m, nnz, h, f, P(W.row_ptr), P(W.col_ind), P(W.Q), P(W.K), P(W.V), P(rmax), P(rsum),
+        return L.dfgnn_gt_bwd_stats(m, nnz, h, f, P(W.row_ptr), P(W.col_ind), None, P(W.Q), P(W.K), P(W.V), P(rmax), P(rsum),
                                     P(W.dO), P(dQ), P(dK), P(dV), plan, plan_meta, stream)
 
     def fwd_call(vp):
@@ -355,11 +358,34 @@ def main():
     reps = max(10, args.steps)
     attn_us = {"gt_hyper_fwd": ev_us(checked(fwd_call(VP)), reps), "gt_bwd": ev_us(checked(bwd_call(VP)), reps)}
     attn_bytes = algorithmic_bytes(m, nnz, h, f)
-    if uses_stats:
-        kernel_us = {"gt_hyper_fwd_stats": ev_us(checked(fwd_stats_call), reps), "gt_bwd_stats": ev_us(checked(bwd_stats_call), reps)}
-        abytes = algorithmic_bytes_stats(m, nnz, h, f)
+    stats_us, stats_bytes = None, algorithmic_bytes_stats(m, nnz, h, f)
+    if stats_can is not None:
+        stats_us = {"gt_hyper_fwd_stats": ev_us(checked(fwd_stats_call), reps), "gt_bwd_stats": ev_us(checked(bwd_stats_call), reps)}
+    if uses_stats is not None:
+        kernel_us, abytes = stats_us, stats_bytes
     else:
         kernel_us, abytes = attn_us, attn_bytes
+    # edge values other than ones: the statistics pair with the values in the plan's dense form (what FusedGTFunction_hyper
+    # launches for a weighted batch: csrc/gt_dense_stats_w.hip); the dense form is built once per (plan, val)
+    weighted = None
+    if stats_can is not None and rank == 0:
+        from _binding_util import plan_dense_weights
+        with torch.no_grad():
+            wval = torch.rand(nnz, 1, device=dev) + 0.5
+            t0 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            t0[0].record()
+            wd = plan_dense_weights(stats_can, W.row_ptr, wval)
+            t0[1].record()
+            torch.cuda.synchronize()
+        wf = ev_us(checked(lambda: L.dfgnn_gt_hyper_fwd_stats(m, nnz, h, f, P(W.row_ptr), P(W.col_ind), P(wd), P(W.Q), P(W.K), P(W.V),
+                                                              P(rmax), P(rsum), P(out), plan, plan_meta, stream)), reps)
+        wb = ev_us(checked(lambda: L.dfgnn_gt_bwd_stats(m, nnz, h, f, P(W.row_ptr), P(W.col_ind), P(wd), P(W.Q), P(W.K), P(W.V),
+                                                        P(rmax), P(rsum), P(W.dO), P(dQ), P(dK), P(dV), plan, plan_meta, stream)), reps)
+        weighted = {"what": "fwd + bwd with edge values (uniform in [0.5, 1.5)) on the matrix cores: statistics pair, values in the "
+                            "plan's dense form (256 floats per node, built once per (plan, val))",
+                    "fwd_us": round(wf, 2), "bwd_us": round(wb, 2), "edges_per_s": nnz / ((wf + wb) * 1e-6),
+                    "dense_form_build_us": round(t0[0].elapsed_time(t0[1]) * 1e3, 1)}
+        del wd, wval
     # the same two launches with the edge values passed explicitly (val != NULL): the matrix-core kernels step aside and
     # every product is an fp32 FMA on the VALU (the LDS-resident edge-walking kernels) -- the plain-f32 reference point
     valu_us = {"gt_hyper_fwd": ev_us(checked(fwd_call(P(W.val))), reps), "gt_bwd": ev_us(checked(bwd_call(P(W.val))), reps)}
@@ -401,8 +427,9 @@ def main():
         "products": "matrix cores (v_mfma_f32_16x16x32_f16): every operand as fp16 hi + lo halves under a power-of-two scale, "
                     "hi*hi + hi*lo + lo*hi accumulated in fp32 (~3 x 2^-24 relative error per product, that of an fp32 FMA "
                     "chain; tests/test_gpu_parity.py::test_dense_kernels_are_fp32_equivalent)",
-        "f32_valu_step": {"what": "the same fwd+bwd launches with every product as an fp32 FMA on the VALU (edge values "
-                                  "passed explicitly, so the matrix-core kernels step aside)",
+        "f32_valu_step": {"what": "the attn_edge pair's fwd+bwd launches with every product as an fp32 FMA on the VALU (edge "
+                                  "values passed explicitly to dfgnn_gt_hyper_fwd / dfgnn_gt_bwd, which have no matrix-core "
+                                  "form for them)",
                           "fwd_us": round(valu_us["gt_hyper_fwd"], 2), "bwd_us": round(valu_us["gt_bwd"], 2),
                           "edges_per_s": nnz / (valu_step_us * 1e-6),
                           "frac_fwd": round(attn_bytes["gt_hyper_fwd"] / (valu_us["gt_hyper_fwd"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
@@ -437,7 +464,7 @@ def main():
 
         def raw_step():  # the launches of the timed step as explicit operator calls (no autograd bookkeeping)
             with torch.no_grad():
-                if uses_stats:
+                if uses_stats is not None:
                     o, mx_, sm_ = fused_gtconv.gt_hyper_forward_stats(W.row_ptr, W.col_ind, W.Q, W.K, W.V)
                     return fused_gtconv.gt_backward_stats(W.row_ptr, W.col_ind, W.Q, W.K, W.V, mx_, sm_, W.dO)
                 o, at = fused_gtconv.gt_hyper_forward(W.row_ptr, W.col_ind, W.rows, W.val, W.col_ptr, W.row_ind, W.val_idx,
@@ -451,6 +478,11 @@ def main():
             # launches as round 2's headline; SURVEY.md 8(d) bytes
             "attn_edge_pair": {k: {"avg_us": round(v, 2), "algorithmic_bytes": attn_bytes[k],
                                    "frac": round(attn_bytes[k] / (v * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)} for k, v in attn_us.items()},
+            # the pair that saves row statistics instead of attn_edge (what the step launches from two heads on)
+            "weighted_edges": weighted,
+            "row_statistics_pair": None if stats_us is None else {
+                k: {"avg_us": round(v, 2), "algorithmic_bytes": stats_bytes[k],
+                    "frac": round(stats_bytes[k] / (v * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)} for k, v in stats_us.items()},
             "gat_train": {"fwd_us": round(gat_f, 1), "bwd_us": round(gat_b, 1),
                           "edges_per_s": nnz / ((gat_f + gat_b) * 1e-6)},
             "preprocess_per_batch_ms": {
@@ -513,7 +545,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "arithmetic": arithmetic, "data": "synthetic",
             "config": {"workload": f"GT conv 'hyper' fwd+bwd, PATTERN-like batch bs={args.batch_size} "
                                    f"dim={args.dim} heads={h} (BASELINE.json configs[2])",
-                       "training_pair": "row statistics (dfgnn_gt_hyper_fwd_stats / dfgnn_gt_bwd_stats)" if uses_stats
+                       "training_pair": "row statistics (dfgnn_gt_hyper_fwd_stats / dfgnn_gt_bwd_stats)" if uses_stats is not None
                        else "attn_edge (dfgnn_gt_hyper_fwd / dfgnn_gt_bwd)",
                        "nodes_per_gpu": m, "edges_per_gpu": nnz, "total_edges": total_edges,
                        "parallelism": (f"graph-sharded x{world} ({args.scaling} scaling), no data-path collective")},

@@ -24,18 +24,19 @@ class FusedGTFunction_hyper(torch.autograd.Function):
     """Fused forward + fused backward.  reference :79-158
 
     The reference's forward saves the normalised attention (attn_edge[h, nnz]) for the backward.  When the whole batch
-    runs on the matrix-core kernels (fused_gt.gt_stats_pair_applies: a block plan of dense ranges, unit edge values)
-    the forward saves two floats per (row, head) instead -- logit maximum and sum of exponentials -- and the backward
+    runs on the matrix-core kernels (fused_gt.gt_stats_pair_applies: a block plan of dense ranges) and has at least two
+    heads or edge values other than ones (fused_gt.gt_stats_pair_chosen: there it is the faster pair, measured) the
+    forward saves two floats per (row, head) instead -- logit maximum and sum of exponentials -- and the backward
     recomputes the attention (include/dfgnn.h: dfgnn_gt_hyper_fwd_stats / dfgnn_gt_bwd_stats): same gradients, 8 h nnz
     bytes less through HBM.  Any other batch takes the reference's form below it."""
 
     @staticmethod
     def forward(ctx, rows, row_ptr, col_ind, val, col_ptr, row_ind, val_idx, smem_consume, Q, K, V):
         ctx.smem = smem_consume
-        ctx.stats = fused_gt.gt_stats_pair_applies(row_ptr, col_ind, val, Q)   # the block plan, or None
+        ctx.stats = fused_gt.gt_stats_pair_chosen(row_ptr, col_ind, val, Q)   # the block plan, or None
         if ctx.stats is not None:
-            out_feat, row_max, row_sum = fused_gt.gt_hyper_forward_stats(row_ptr, col_ind, Q, K, V, ctx.stats)
-            ctx.save_for_backward(row_ptr, col_ind, Q, K, V, row_max, row_sum)
+            out_feat, row_max, row_sum = fused_gt.gt_hyper_forward_stats(row_ptr, col_ind, Q, K, V, ctx.stats, val)
+            ctx.save_for_backward(row_ptr, col_ind, Q, K, V, row_max, row_sum, val)
             return out_feat
         out_feat, attn_edge = fused_gt.gt_hyper_forward(
             row_ptr, col_ind, rows, val, col_ptr, row_ind, val_idx, smem_consume, Q, K, V)
@@ -45,9 +46,9 @@ class FusedGTFunction_hyper(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out):
         if ctx.stats is not None:
-            row_ptr, col_ind, Q, K, V, row_max, row_sum = ctx.saved_tensors
+            row_ptr, col_ind, Q, K, V, row_max, row_sum, val = ctx.saved_tensors
             grad_Q, grad_K, grad_V = fused_gt.gt_backward_stats(row_ptr, col_ind, Q, K, V, row_max, row_sum,
-                                                                grad_out.contiguous(), ctx.stats)
+                                                                grad_out.contiguous(), ctx.stats, val)
             return (None,) * 8 + (grad_Q, grad_K, grad_V)
         row_ptr, col_ind, rows, val, col_ptr, row_ind, val_idx, Q, K, V, attn_edge = ctx.saved_tensors
         grad_Q, grad_K, grad_V = fused_gt.gt_backward(

@@ -84,6 +84,33 @@ class _KeyedCache:
 _unit_cache = _KeyedCache()
 _plan_cache = _KeyedCache()
 _rows_cache = _KeyedCache()
+_weights_cache = _KeyedCache(entries=4)   # 1 KB per node each
+
+
+def plan_dense_weights(plan, row_ptr, val):
+    """The edge values `val` (fp32[nnz] / [nnz, 1], CSR order) in the dense form the WEIGHTED matrix-core kernels read
+    (include/dfgnn.h: dfgnn_plan_dense_weights): fp32[256 m], built once per (plan, val tensor version) and cached --
+    edge weights of a dataset do not change from step to step."""
+    import dfgnn_native as _n
+    key = _KeyedCache.key_of(val, extra=(plan.key,))
+    w = _weights_cache.get(key)
+    if w is not None:
+        return w
+    v = val.reshape(-1)
+    if v.dtype != torch.float32 or not v.is_contiguous():
+        raise RuntimeError("val must be contiguous float32")
+    ext = _n.ext()
+    pp, mp = plan.ptrs()
+    with torch.cuda.device(val.device):
+        if ext is not None and hasattr(ext, "plan_dense_weights"):
+            w = ext.plan_dense_weights(row_ptr, v, pp, mp)
+        else:
+            L = _n.lib()
+            m, nnz = plan.meta[4], plan.meta[5]
+            w = torch.empty(int(L.dfgnn_plan_dense_weights_floats(m)), dtype=torch.float32, device=val.device)
+            _n.check(L.dfgnn_plan_dense_weights(m, nnz, row_ptr.data_ptr(), v.data_ptr(), pp, mp, w.data_ptr(),
+                                                stream_ptr(val.device)), "plan_dense_weights")
+    return _weights_cache.put(key, w, val, plan)
 
 
 def val_ptr(val):

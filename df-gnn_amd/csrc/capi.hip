@@ -172,20 +172,22 @@ int dfgnn_gt_stats_applies(int m, int nnz, int h, int f, const int *plan_meta) {
   return gt_stats_plan(p, &token, plan_meta, m, nnz, h, f) ? 1 : 0;
 }
 
-int dfgnn_gt_hyper_fwd_stats(int m, int nnz, int h, int f, const int *row_ptr, const int *col_ind, const float *Q,
-                             const float *K, const float *V, float *row_max, float *row_sum, float *out,
+int dfgnn_gt_hyper_fwd_stats(int m, int nnz, int h, int f, const int *row_ptr, const int *col_ind, const float *weights,
+                             const float *Q, const float *K, const float *V, float *row_max, float *row_sum, float *out,
                              const int *plan, const int *plan_meta, dfgnn_stream_t stream) {
   if (int c = check_common(m, nnz, h, f, row_ptr, col_ind)) return c < 0 ? c : 0;
-  if (!Q || !K || !V || !out || !row_max || !row_sum) return kErrBadArg;
+  if (!Q || !K || !V || !out || (!row_max != !row_sum)) return kErrBadArg;  // (both statistics or neither: inference)
   Plan p;
   if (!(aligned16(Q) && aligned16(K) && aligned16(V) && aligned16(out)) || !gt_stats_plan(p, plan, plan_meta, m, nnz, h, f))
     return kErrUnsupported;
-  const Csr g{m, nnz, h, f, row_ptr, col_ind, nullptr, nullptr};
+  if (weights && !aligned16(weights)) return kErrUnsupported;
+  Csr g{m, nnz, h, f, row_ptr, col_ind, nullptr, nullptr};
+  g.wdense = weights;
   return launch_gt_dense_fwd_stats(g, p, Q, K, V, out, row_max, row_sum, as_stream(stream));
 }
 
-int dfgnn_gt_bwd_stats(int m, int nnz, int h, int f, const int *row_ptr, const int *col_ind, const float *Q,
-                       const float *K, const float *V, const float *row_max, const float *row_sum,
+int dfgnn_gt_bwd_stats(int m, int nnz, int h, int f, const int *row_ptr, const int *col_ind, const float *weights,
+                       const float *Q, const float *K, const float *V, const float *row_max, const float *row_sum,
                        const float *grad_out, float *dQ, float *dK, float *dV, const int *plan, const int *plan_meta,
                        dfgnn_stream_t stream) {
   if (int c = check_common(m, nnz, h, f, row_ptr, col_ind)) return c < 0 ? c : 0;
@@ -194,7 +196,9 @@ int dfgnn_gt_bwd_stats(int m, int nnz, int h, int f, const int *row_ptr, const i
   if (!(aligned16(Q) && aligned16(K) && aligned16(V) && aligned16(grad_out) && aligned16(dQ) && aligned16(dK) && aligned16(dV)) ||
       !gt_stats_plan(p, plan, plan_meta, m, nnz, h, f))
     return kErrUnsupported;
-  const Csr g{m, nnz, h, f, row_ptr, col_ind, nullptr, nullptr};
+  if (weights && !aligned16(weights)) return kErrUnsupported;
+  Csr g{m, nnz, h, f, row_ptr, col_ind, nullptr, nullptr};
+  g.wdense = weights;
   return launch_gt_dense_bwd_stats(g, p, Q, K, V, row_max, row_sum, grad_out, dQ, dK, dV, as_stream(stream));
 }
 

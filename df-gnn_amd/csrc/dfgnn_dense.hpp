@@ -37,6 +37,40 @@ typedef __attribute__((ext_vector_type(4))) _Float16 hx4;
 typedef __fp16 fp16x4_raw __attribute__((__vector_size__(4 * sizeof(__fp16))));  // the transposed-read builtin's type
 typedef __attribute__((address_space(3))) fp16x4_raw *lds_hx4_ptr;
 
+// ---- debug build: bounds-checked LDS addressing ---------------------------------------------------------------------
+// `make ldscheck` compiles the matrix-core translation units with -DDFGNN_LDS_CHECK into libdfgnn_ldscheck.so.  Every
+// LDS address the helpers of this file form (image stores, row / transposed operand reads, the ld32 / st32 accessors when
+// they are handed an LDS base, the workgroup-maximum slots) is then compared with the workgroup's LDS allocation -- the
+// kernel's static size plus the launch's dynamic size (hidden_dynamic_lds_size, implicit kernel argument 30 of code
+// object v5) -- before it is used.  A violation is COUNTED, not trapped (a trapping kernel can take the GPU down for
+// everyone on the host; the hardware itself drops out-of-range LDS accesses): the first one's source line, byte offset and
+// limit are kept and dfgnn_debug_lds_report() (capi.hip, that build only) hands them to the host, summed over the
+// translation units.  tests/test_gpu_ldscheck.py runs the parity workloads through that library.
+#if defined(DFGNN_LDS_CHECK)
+__attribute__((used)) static __device__ unsigned g_lds_report[4];  // violations, line of the first, its end offset, the limit
+__device__ __forceinline__ void lds_check(const void *p, unsigned bytes, int line) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (!__builtin_amdgcn_is_shared(p)) return;                      // a global base handed to ld32 / st32
+  const unsigned end = (unsigned)(size_t)p + bytes;               // low half of a generic LDS address = byte offset
+  const unsigned lim = __builtin_amdgcn_groupstaticsize() + ((const unsigned *)__builtin_amdgcn_implicitarg_ptr())[30];
+  if (end > lim && atomicAdd(&g_lds_report[0], 1u) == 0u) {
+    g_lds_report[1] = (unsigned)line;
+    g_lds_report[2] = end;
+    g_lds_report[3] = lim;
+  }
+#endif
+}
+#define DFGNN_LDS_AT(p, bytes) ::dfgnn::lds_check((p), (bytes), __LINE__)
+void lds_report_register(const void *symbol);  // gt_dense.hip: the list dfgnn_debug_lds_report() walks
+namespace {
+struct LdsReportReg {  // one per translation unit that includes this header: each owns a copy of g_lds_report
+  LdsReportReg() { lds_report_register(HIP_SYMBOL(g_lds_report)); }
+} g_lds_report_reg;
+}  // namespace
+#else
+#define DFGNN_LDS_AT(p, bytes) ((void)0)
+#endif
+
 // Power-of-two scale of an operand whose largest magnitude is amax: s amax lies in [2^14, 2^15), inv = 1 / s.
 // (amax = 0 or subnormal: the largest normal scale; inf / nan inputs give inf / nan outputs, as in fp32.)
 struct Pow2Scale {
@@ -80,12 +114,15 @@ struct DenseCfg {
 // (global_load ... v_off, s[base]) instead of materialising a 64-bit address per access.
 template <class T>
 __device__ __forceinline__ const T &ld32(const T *base, unsigned idx) {
+  DFGNN_LDS_AT(reinterpret_cast<const char *>(base) + (size_t)(idx * (unsigned)sizeof(T)), (unsigned)sizeof(T));
   return *reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + (size_t)(idx * (unsigned)sizeof(T)));
 }
 __device__ __forceinline__ float4 ld32_f4(const float *base, unsigned idx) {  // 4 floats starting at base[idx]
+  DFGNN_LDS_AT(reinterpret_cast<const char *>(base) + (size_t)(idx * 4u), 16u);
   return *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(base) + (size_t)(idx * 4u));
 }
 __device__ __forceinline__ void st32_f4(float *base, unsigned idx, const float4 &v) {
+  DFGNN_LDS_AT(reinterpret_cast<char *>(base) + (size_t)(idx * 4u), 16u);
   *reinterpret_cast<float4 *>(reinterpret_cast<char *>(base) + (size_t)(idx * 4u)) = v;
 }
 
@@ -152,9 +189,11 @@ __device__ __forceinline__ float dense_stage_absmax(const DenseStageRegs<F, ROWS
 // barrier has passed (every caller has one: the barrier that publishes what was converted with the result).
 __device__ __forceinline__ void wg_max_post(float *slot, float v) {
   v = wave_max(v);
+  DFGNN_LDS_AT(slot + threadIdx.x / kWave, 4u);
   if ((threadIdx.x & (kWave - 1)) == 0) slot[threadIdx.x / kWave] = v;
 }
 __device__ __forceinline__ float wg_max_read(const float *slot) {
+  DFGNN_LDS_AT(slot, 32u);
   const float4 a = *reinterpret_cast<const float4 *>(slot), b = *reinterpret_cast<const float4 *>(slot + 4);
   return fmaxf(fmaxf(fmaxf(a.x, a.y), fmaxf(a.z, a.w)), fmaxf(fmaxf(b.x, b.y), fmaxf(b.z, b.w)));
 }
@@ -178,6 +217,8 @@ __device__ __forceinline__ void dense_stage_store(DenseStageRegs<F, ROWS> &r, h1
       const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
       hx8 h, l;
       split_hx8(valid ? r.a[k] : z, valid ? r.b[k] : z, scale, h, l);
+      DFGNN_LDS_AT(hi + row * RS + 8 * c8, 16u);
+      DFGNN_LDS_AT(lo + row * RS + 8 * c8, 16u);
       *reinterpret_cast<hx8 *>(hi + row * RS + 8 * c8) = h;
       *reinterpret_cast<hx8 *>(lo + row * RS + 8 * c8) = l;
     }
@@ -193,6 +234,8 @@ __device__ __forceinline__ void dense_rows_frag(hx8 (&ah)[F / 32], hx8 (&al)[F /
   const int off = (16 * u + L.mi) * RS + 8 * L.mq;
 #pragma unroll
   for (int t = 0; t < F / 32; ++t) {
+    DFGNN_LDS_AT(ihi + off + 32 * t, 16u);
+    DFGNN_LDS_AT(ilo + off + 32 * t, 16u);
     ah[t] = *reinterpret_cast<const hx8 *>(ihi + off + 32 * t);
     al[t] = *reinterpret_cast<const hx8 *>(ilo + off + 32 * t);
   }
@@ -234,6 +277,8 @@ __device__ __forceinline__ void dense_rows_mma_strip(f32x4 (&out)[NTILES], const
 
 // Two transposed 4-row reads -> one 8-element operand fragment (rows r .. r+3 and r + second .. of a column).
 __device__ __forceinline__ hx8 dense_tr_pair(const h16 *p, int second_offset) {
+  DFGNN_LDS_AT(p, 8u);
+  DFGNN_LDS_AT(p + second_offset, 8u);
   const hx4 a = __builtin_bit_cast(hx4, __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_hx4_ptr)(p)));
   const hx4 b = __builtin_bit_cast(hx4, __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_hx4_ptr)(p + second_offset)));
   return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);

@@ -38,7 +38,8 @@ struct GatBwdArgs {
 // strip's Q rows come straight from memory as register operands, as in the forward), masked with the plan's edge bitmap
 // of the lane's row (g.mask), p = 2^(S c - max c) / sum with the forward's row statistics (ga.edge_max / ga.edge_sum) --
 // and written to the tile by its strips; no edge list, no scatter, no clearing of the tile.
-template <int FR, int CW, int NBLK, bool GAT = false, bool RECOMP = false>
+// WEIGHTED (with RECOMP; g.wdense = the plan's dense edge values): logits S val, and dS val for dQ / dK (see dense_bwd_rc2_body).
+template <int FR, int CW, int NBLK, bool GAT = false, bool RECOMP = false, bool WEIGHTED = false>
 __device__ __forceinline__ void dense_bwd_body(float *lds, const Csr &g, int n0, int n, int e0, int ne, int head,
                                                const float *__restrict__ Q, const float *__restrict__ K,
                                                const float *__restrict__ V, const float *__restrict__ attn_edge,
@@ -68,6 +69,7 @@ __device__ __forceinline__ void dense_bwd_body(float *lds, const Csr &g, int n0,
   float *smax = T + RBP * TS;            // [8] per-wave maxima of the image being staged, [8] of the dS tile
   float *arl = smax + 2 * kDenseWaves, *acl = arl + SN, *mxl = acl + SN, *ivl = mxl + SN;
   (void)arl, (void)acl, (void)mxl, (void)ivl;
+  DFGNN_LDS_AT(lds, (unsigned)(reinterpret_cast<char *>(GAT ? ivl + SN : arl) - reinterpret_cast<char *>(lds)));  // the carve-up fits
 
   DFGNN_DSTAMP(0)
   if constexpr (GAT) {
@@ -379,6 +381,10 @@ __device__ __forceinline__ void dense_bwd_body(float *lds, const Csr &g, int n0,
           for (int u = 0; u < U; ++u) {
             const int ug = jc * U + u;
             const unsigned bits = (mwd[ug / 2] >> (16 * (ug & 1) + 4 * L.mq)) & 0xFu;
+            if constexpr (WEIGHTED) {
+              const float4 wv = ld32_f4(g.wdense + (size_t)(n0 + min(irow, n - 1)) * kPlanWeightStride + 4 * L.mq, 16u * ug);
+              S[u][0] *= wv.x; S[u][1] *= wv.y; S[u][2] *= wv.z; S[u][3] *= wv.w;
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               Pr[jc][u][r] = ((bits >> r) & 1u) ? __builtin_amdgcn_exp2f(fmaf(S[u][r], c2, -b2)) : 0.f;
@@ -548,10 +554,26 @@ __device__ __forceinline__ void dense_bwd_body(float *lds, const Csr &g, int n0,
 #pragma unroll
         for (int u = 0; u < U; ++u)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            dS[jc][u][r] = Pr[jc][u][r] * (dS[jc][u][r] - t);
-            tmax = fmaxf(tmax, fabsf(dS[jc][u][r]));
+          for (int r = 0; r < 4; ++r) dS[jc][u][r] = Pr[jc][u][r] * (dS[jc][u][r] - t);
+      if constexpr (WEIGHTED) {  // d logit / d S = val (P is exactly zero off the edges)
+        const LaneIds L = lane_ids();
+        const float *wrow = g.wdense + (size_t)(n0 + min(i0 + wave * 16 + L.mi, n - 1)) * kPlanWeightStride + 4 * L.mq;
+#pragma unroll
+        for (int jc = 0; jc < NBLK; ++jc)
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            const float4 wv = ld32_f4(wrow, 16u * (jc * U + u));
+            const float wvr[4] = {wv.x, wv.y, wv.z, wv.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dS[jc][u][r] = (Pr[jc][u][r] != 0.f) ? dS[jc][u][r] * wvr[r] : 0.f;
           }
+      }
+#pragma unroll
+      for (int jc = 0; jc < NBLK; ++jc)
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) tmax = fmaxf(tmax, fabsf(dS[jc][u][r]));
     }
     if constexpr (!GAT) {
       wg_max_post(smax + kDenseWaves, tmax);  // the dS tile's scale needs the largest |dS| of the row block

@@ -24,7 +24,9 @@
 
 namespace dfgnn {
 
-template <int FR>
+// WEIGHTED (g.wdense: the plan's dense edge values): the logit of an edge is S val, and d logit / d S = val multiplies dS
+// before it is used for dQ and dK (the reference's attn * val, fused_gtconv_hyper.cu:88-90, differentiated).
+template <int FR, bool WEIGHTED = false>
 __device__ __forceinline__ void dense_bwd_rc2_body(float *lds, const Csr &g, int n0, int n, int head,
                                                    const float *__restrict__ Q, const float *__restrict__ K,
                                                    const float *__restrict__ V, const float *__restrict__ stat_max,
@@ -42,6 +44,7 @@ __device__ __forceinline__ void dense_bwd_rc2_body(float *lds, const Csr &g, int
   constexpr size_t kImgB = 2 * (size_t)CW * RS, kTileH = (size_t)CW * TB;  // fp16 elements
   h16 *Tb = bhi;                                                          // the tile: CW rows of hi[TS] | lo[TS]
   float *smax = reinterpret_cast<float *>(bhi + (kImgB > kTileH ? kImgB : kTileH));  // [3][8]: image A, image B, dS
+  DFGNN_LDS_AT(lds, (unsigned)(reinterpret_cast<char *>(smax + 3 * kDenseWaves) - reinterpret_cast<char *>(lds)));  // the carve-up fits
   const size_t hf = (size_t)g.h * fr, hoff = (size_t)head * fr;
   const float *Qb = Q + (size_t)n0 * hf + hoff, *Kb = K + (size_t)n0 * hf + hoff, *Vb = V + (size_t)n0 * hf + hoff,
               *dOb = dO + (size_t)n0 * hf + hoff;
@@ -190,9 +193,14 @@ __device__ __forceinline__ void dense_bwd_rc2_body(float *lds, const Csr &g, int
       // with logits of +-100 the two differ by 1e-5 relative, and sum_j P_ij = 1 is what the softmax Jacobian assumes);
       // the forward's m_i only has to be near the maximum.  sinv just says whether the row has edges at all.
       float t = 0.f, l = 0.f;
+      const float *wrow = WEIGHTED ? g.wdense + (size_t)(n0 + min(wave * 16 + L.mi, n - 1)) * kPlanWeightStride + 4 * L.mq : nullptr;
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const unsigned bits = (mwd[u / 2] >> (16 * (u & 1) + 4 * L.mq)) & 0xFu;
+        if constexpr (WEIGHTED) {
+          const float4 wv = (16 * u < n) ? ld32_f4(wrow, 16u * u) : make_float4(0.f, 0.f, 0.f, 0.f);
+          P[u][0] *= wv.x; P[u][1] *= wv.y; P[u][2] *= wv.z; P[u][3] *= wv.w;
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float p = ((bits >> r) & 1u) ? __builtin_amdgcn_exp2f(fmaf(P[u][r], c2, -smx)) : 0.f;
@@ -210,10 +218,21 @@ __device__ __forceinline__ void dense_bwd_rc2_body(float *lds, const Csr &g, int
 #pragma unroll
       for (int u = 0; u < U; ++u)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          dS[u][r] = P[u][r] * (dS[u][r] - t);
-          tmax = fmaxf(tmax, fabsf(dS[u][r]));
+        for (int r = 0; r < 4; ++r) dS[u][r] = P[u][r] * (dS[u][r] - t);
+      if constexpr (WEIGHTED) {  // (dS is zero off the edges: whatever the weight rows hold there is not read as a factor of a non-zero)
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const unsigned bits = (mwd[u / 2] >> (16 * (u & 1) + 4 * L.mq)) & 0xFu;
+          const float4 wv = (16 * u < n) ? ld32_f4(wrow, 16u * u) : make_float4(0.f, 0.f, 0.f, 0.f);
+          const float wvr[4] = {wv.x, wv.y, wv.z, wv.w};
+#pragma unroll
+          for (int r = 0; r < 4; ++r) dS[u][r] = ((bits >> r) & 1u) ? dS[u][r] * wvr[r] : 0.f;
         }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) tmax = fmaxf(tmax, fabsf(dS[u][r]));
       // dQ^T = K^T dS^T: the dS strip is the operand as it stands (under this strip's own scale)
       const Pow2Scale tw = pow2_scale(wave_max(tmax));
       f32x4 qacc[FT];

@@ -27,7 +27,7 @@ struct DenseDrop {
 // STATS (GT training forward of the statistics-saving pair, gt_dense_stats.hip): the edge set comes from the plan's
 // bitmaps (g.mask: each lane fetches the words of its own rows straight from memory -- no byte map, no edge list, no
 // row pointers), the normalised attention is not written, the row statistics (logit maximum, sum of exponentials) are.
-template <int FR, bool WRITE_ATTN, int NS, int CR, int NCH, bool GAT = false, bool MULTI = false, bool STATS = false>
+template <int FR, bool WRITE_ATTN, int NS, int CR, int NCH, bool GAT = false, bool MULTI = false, bool STATS = false, bool WEIGHTED = false>
 __device__ __forceinline__ void dense_fwd_body(float *lds, int lds_bytes, const Csr &g, int n0, int n, int e0, int ne,
                                                int head, int nheads, const float *__restrict__ Q,
                                                const float *__restrict__ K, const float *__restrict__ V,
@@ -39,6 +39,7 @@ __device__ __forceinline__ void dense_fwd_body(float *lds, int lds_bytes, const 
   static_assert(!(STATS && (WRITE_ATTN || GAT)), "the statistics-saving forward writes no attention values");
   constexpr int F = FR < 32 ? 32 : FR;  // layout width
   constexpr int fr = FR;
+  static_assert(!WEIGHTED || (STATS && !GAT), "dense edge values go with the bitmap-masked (STATS) GT forward");
   using D = DenseCfg<F>;
   constexpr int RS = D::RS, KT = D::KT, FT = D::FT, TPC = CR / 16, NT = TPC * NCH;
   constexpr int MW = (NT + 1) / 2;  // bitmap words of a row (STATS)
@@ -54,6 +55,7 @@ __device__ __forceinline__ void dense_fwd_body(float *lds, int lds_bytes, const 
   float *pstage = acl + (GAT ? npad : 0);                          // [ne] normalised attention values, if it fits
   const size_t fixed_bytes = (size_t)(reinterpret_cast<char *>(pstage) - reinterpret_cast<char *>(lds));
   const bool stage_attn = WRITE_ATTN && fixed_bytes + ((size_t)ne + kDenseThreads) * 4 <= (size_t)lds_bytes;  // (+ dump words)
+  DFGNN_LDS_AT(lds, (unsigned)(fixed_bytes + (stage_attn ? ((size_t)ne + kDenseThreads) * 4 : 0)));  // the carve-up fits
   // GT: the workgroup takes the heads head .. head + nheads - 1 of its range one after the other -- the edge loads and
   // the byte map are shared, the next head's K image and Q rows travel while the current head's P V product runs
   // (GAT: nheads = 1; its attn_col staging and dropout map are per head)
@@ -258,6 +260,9 @@ __device__ __forceinline__ void dense_fwd_body(float *lds, int lds_bytes, const 
       // row maximum is taken on them as they are and the factor -- times log2 e -- goes into the exponent's FMA:
       // p = 2^(S c2 - max c2).  Two chunks have a scale each: the logits are formed first.
       constexpr bool kFold = NCH == 1;
+      // WEIGHTED: the logit of an edge is S val (the reference's attn * val, fused_gtconv_hyper.cu:88-90), val from the
+      // dense weight rows of the plan; the common positive factor of the accumulators still folds into the exponent
+      const float *wrow = WEIGHTED ? g.wdense + (size_t)(n0 + min(i, n - 1)) * kPlanWeightStride + 4 * L.mq : nullptr;
       const float c2 = (GAT ? 1.f : kinv[0] * qinv[s]) * 1.4426950408889634f;
       float mx = -INFINITY;
 #pragma unroll
@@ -265,10 +270,15 @@ __device__ __forceinline__ void dense_fwd_body(float *lds, int lds_bytes, const 
         unsigned w = 0xFFFFFFFFu, wb = 0u;
         if constexpr (STATS) wb = stat_bits(jt);
         else w = (jt < ntile) ? *reinterpret_cast<const unsigned *>(mrow + 16 * jt) : 0xFFFFFFFFu;
+        float4 wv = make_float4(1.f, 1.f, 1.f, 1.f);
+        if constexpr (WEIGHTED)
+          if (jt < ntile) wv = ld32_f4(wrow, 16u * jt);
+        const float wvr[4] = {wv.x, wv.y, wv.z, wv.w};
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const bool edge = STATS ? ((wb >> r) & 1u) != 0u : ((w >> (8 * r)) & 0xFFu) != 0xFFu;
-          const float x = edge ? ((GAT || kFold) ? S[s][jt][r] : S[s][jt][r] * (kinv[jt / TPC] * qinv[s])) : -INFINITY;
+          float x = edge ? ((GAT || kFold) ? S[s][jt][r] : S[s][jt][r] * (kinv[jt / TPC] * qinv[s])) : -INFINITY;
+          if constexpr (WEIGHTED) x = edge ? x * wvr[r] : x;
           S[s][jt][r] = x;
           mx = fmaxf(mx, x);
         }

@@ -82,6 +82,7 @@ __device__ __forceinline__ void dense_fwd_heads_body(float *lds, int lds_bytes, 
   const int fixed_bytes = (int)(reinterpret_cast<char *>(stage0) - reinterpret_cast<char *>(lds));
   const int cap = (((lds_bytes - fixed_bytes) / kDenseWaves) / 4 - kWave) & ~3;
   float *wstage = stage0 + wave * (max(cap, 0) + kWave);
+  DFGNN_LDS_AT(lds, (unsigned)fixed_bytes + (WRITE_ATTN ? (unsigned)(kDenseWaves * (max(cap, 0) + kWave) * 4) : 0u));  // the carve-up fits
   const size_t hf = (size_t)g.h * FR;
   const float *Qb = Q + (size_t)n0 * hf, *Kb = K + (size_t)n0 * hf, *Vb = V + (size_t)n0 * hf;
   float *Ob = out + (size_t)n0 * hf;
@@ -463,6 +464,7 @@ __device__ __forceinline__ void dense_bwd_heads_body(float *lds, const Csr &g, i
   h16 *bhi = alo + (size_t)NP * RS, *blo = bhi + (size_t)NP * RS;         // buffer B: V, then Q
   h16 *Tb = blo + (size_t)NP * RS;                                        // the tile: NP rows of hi[TS] | lo[TS]
   float *smax = reinterpret_cast<float *>(Tb + (size_t)NP * TB);          // [3][8] per-wave maxima: image A, image B, dS
+  DFGNN_LDS_AT(lds, (unsigned)(reinterpret_cast<char *>(smax + 3 * kDenseWaves) - reinterpret_cast<char *>(lds)));  // the carve-up fits
   const size_t hf = (size_t)g.h * fr;
   const float *Qb = Q + (size_t)n0 * hf, *Kb = K + (size_t)n0 * hf, *Vb = V + (size_t)n0 * hf, *dOb = dO + (size_t)n0 * hf;
   float *dQb = dQ + (size_t)n0 * hf, *dKb = dK + (size_t)n0 * hf, *dVb = dV + (size_t)n0 * hf;

@@ -57,6 +57,7 @@ __device__ __forceinline__ void dense_bwd_heads2_body(float *lds, const Csr &g, 
   float *smxl = tarr + G * NP;                                           // [G][NP] m_i log2(e)
   float *sinvl = smxl + G * NP;                                          // [G][NP] 1 / l_i
   float *smax = sinvl + G * NP;                                          // [2][8] per-wave maxima of the two images
+  DFGNN_LDS_AT(lds, (unsigned)(reinterpret_cast<char *>(smax + 2 * kDenseWaves) - reinterpret_cast<char *>(lds)));  // the carve-up fits
   const size_t hf = (size_t)g.h * FR;
   const float *Qb = Q + (size_t)n0 * hf, *Kb = K + (size_t)n0 * hf, *Vb = V + (size_t)n0 * hf, *dOb = dO + (size_t)n0 * hf;
   float *dQb = dQ + (size_t)n0 * hf, *dKb = dK + (size_t)n0 * hf, *dVb = dV + (size_t)n0 * hf;

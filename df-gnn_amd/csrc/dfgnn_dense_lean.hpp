@@ -51,6 +51,7 @@ __global__ __launch_bounds__(kLeanThreads, 2) void gt_dense_fwd_lean_kernel(Csr 
   float *pstage = smax + 4;                                       // [ne] normalised attention values, if it fits
   const size_t fixed_bytes = (size_t)(reinterpret_cast<char *>(pstage) - reinterpret_cast<char *>(lds));
   const bool stage_attn = WRITE_ATTN && fixed_bytes + (size_t)ne * 4 <= (size_t)kLeanLdsBytes;
+  DFGNN_LDS_AT(lds, (unsigned)(fixed_bytes + (stage_attn ? (size_t)ne * 4 : 0)));  // the carve-up fits
   const size_t hf = (size_t)g.h * F, hoff = (size_t)head * F;
   const float *Qb = Q + (size_t)n0 * hf + hoff, *Kb = K + (size_t)n0 * hf + hoff, *Vb = V + (size_t)n0 * hf + hoff;
   float *Ob = out + (size_t)n0 * hf + hoff;

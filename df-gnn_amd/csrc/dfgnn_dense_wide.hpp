@@ -35,7 +35,8 @@ extern __device__ unsigned long long *dfgnn_dense_stamps;
 // K.h -> S += Q.h K.h^T, the strips' Q rows straight from memory as register operands -- then P = 2^(S c - max c) / sum
 // on the edges of the plan's bitmap (g.mask) with the forward's row statistics (stat_max, stat_sum: [m, h]), written to
 // the tile by its strips (every row of the tile: nothing is cleared, nothing scattered).
-template <int FR, int NP, int R, int FWMAX = 64, bool RECOMP = false>
+// WEIGHTED (with RECOMP; g.wdense = the plan's dense edge values): logits S val, and dS val for dQ / dK (see dense_bwd_rc2_body).
+template <int FR, int NP, int R, int FWMAX = 64, bool RECOMP = false, bool WEIGHTED = false>
 __device__ __forceinline__ void dense_bwd_wide_body(float *lds, const Csr &g, int n0, int n, int e0, int ne, int head,
                                                     const float *__restrict__ Q, const float *__restrict__ K,
                                                     const float *__restrict__ V, const float *__restrict__ attn_edge,
@@ -57,6 +58,7 @@ __device__ __forceinline__ void dense_bwd_wide_body(float *lds, const Csr &g, in
   float *T = reinterpret_cast<float *>(ilo + (size_t)NP * RS);
   h16 *Tb = reinterpret_cast<h16 *>(T);
   float *smax = T + NP * TS;  // [8] image maxima, [8] dS maxima
+  DFGNN_LDS_AT(lds, (unsigned)(reinterpret_cast<char *>(smax + 2 * kDenseWaves) - reinterpret_cast<char *>(lds)));  // the carve-up fits
   const size_t hf = (size_t)g.h * FR, hoff = (size_t)head * FR;
   const float *Qb = Q + (size_t)n0 * hf + hoff, *Kb = K + (size_t)n0 * hf + hoff, *Vb = V + (size_t)n0 * hf + hoff,
               *dOb = dO + (size_t)n0 * hf + hoff;
@@ -185,9 +187,14 @@ __device__ __forceinline__ void dense_bwd_wide_body(float *lds, const Csr &g, in
         const float b = smx[s];
         // normalised by their own row sum (see dense_bwd_rc2_body): sum_j P_ij = 1 for the P that is differentiated
         float lsum = 0.f;
+        const float *wrow = WEIGHTED ? g.wdense + (size_t)(n0 + min(strip * 16 + L.mi, n - 1)) * kPlanWeightStride + 4 * L.mq : nullptr;
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           const unsigned bits = (mwd[s][u / 2] >> (16 * (u & 1) + 4 * L.mq)) & 0xFu;
+          if constexpr (WEIGHTED) {
+            const float4 wv = ld32_f4(wrow, 16u * u);
+            S[s][u][0] *= wv.x; S[s][u][1] *= wv.y; S[s][u][2] *= wv.z; S[s][u][3] *= wv.w;
+          }
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             S[s][u][r] = ((bits >> r) & 1u) ? fast_exp(S[s][u][r] - b) : 0.f;
@@ -368,9 +375,15 @@ __device__ __forceinline__ void dense_bwd_wide_body(float *lds, const Csr &g, in
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const hx4 ph = *reinterpret_cast<const hx4 *>(prow + 16 * u), pl = *reinterpret_cast<const hx4 *>(prow + TS + 16 * u);
+        float4 wv = make_float4(1.f, 1.f, 1.f, 1.f);  // WEIGHTED: d logit / d S (P is exactly zero off the edges)
+        if constexpr (WEIGHTED)
+          wv = ld32_f4(g.wdense + (size_t)(n0 + min(strip * 16 + L.mi, n - 1)) * kPlanWeightStride + 4 * L.mq, 16u * u);
+        const float wvr[4] = {wv.x, wv.y, wv.z, wv.w};
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          dP[s][u][r] = ((float)ph[r] + (float)pl[r]) * kUnitScaleInv * (dP[s][u][r] - t);
+          const float p = ((float)ph[r] + (float)pl[r]) * kUnitScaleInv;
+          dP[s][u][r] = p * (dP[s][u][r] - t);
+          if constexpr (WEIGHTED) dP[s][u][r] = (p != 0.f) ? dP[s][u][r] * wvr[r] : 0.f;
           tmax = fmaxf(tmax, fabsf(dP[s][u][r]));
         }
       }

@@ -19,7 +19,12 @@ struct Csr {
   // the node c places after the first node of its range; maskT likewise for the edges INTO node i.  Read by the
   // statistics-saving training pair (gt_dense_stats.hip), which needs to know where the edges are but not their order.
   const unsigned *mask = nullptr, *maskT = nullptr;
+  // edge VALUES of the dense ranges in dense form (plan.hip: plan_dense_weights), kPlanWeightStride floats per node:
+  // wdense[256 i + c] = val of the edge from node i to the node c places after the first node of its range.  Read by the
+  // WEIGHTED instances of the statistics-saving pair (gt_dense_stats_w.hip) wherever the edge bitmap has a bit; null = unit values
+  const float *wdense = nullptr;
 };
+constexpr int kPlanWeightStride = 256;
 
 constexpr int kErrBadArg = -1;
 constexpr int kErrUnsupported = -2;
@@ -121,6 +126,13 @@ int launch_gt_dense_fwd_stats(const Csr &g, const Plan &p, const float *Q, const
 int launch_gt_dense_bwd_stats(const Csr &g, const Plan &p, const float *Q, const float *K, const float *V,
                               const float *stat_max, const float *stat_sum, const float *grad_out, float *dQ, float *dK,
                               float *dV, hipStream_t s);
+// ... with edge values (gt_dense_stats_w.hip): g.wdense = the plan's dense weights (dfgnn_plan_dense_weights); the two
+// launchers above hand over to these when g.wdense is set.  stat_max / stat_sum of the forward may be null (inference).
+int launch_gt_dense_fwd_stats_w(const Csr &g, const Plan &p, const float *Q, const float *K, const float *V, float *out,
+                                float *stat_max, float *stat_sum, hipStream_t s);
+int launch_gt_dense_bwd_stats_w(const Csr &g, const Plan &p, const float *Q, const float *K, const float *V,
+                                const float *stat_max, const float *stat_sum, const float *grad_out, float *dQ, float *dK,
+                                float *dV, hipStream_t s);
 // edge_max / edge_sum (nullable): row statistics for the GAT training pair
 int launch_gat_dense_fwd(const Csr &g, const Plan &p, const float *attn_row, const float *attn_col, float slope,
                          const float *X, float *out, hipStream_t s, float *edge_max = nullptr,

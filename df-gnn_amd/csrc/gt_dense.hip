@@ -335,3 +335,52 @@ int launch_gt_dense_bwd(const Csr &g_in, const Plan &p, const float *Q, const fl
 }
 
 }  // namespace dfgnn
+
+#if defined(DFGNN_LDS_CHECK)  // ---- `make ldscheck` only: the host side of the bounds-checked LDS addressing -------------
+#include <mutex>
+#include <vector>
+namespace dfgnn {
+namespace {
+std::mutex &lds_reports_lock() { static std::mutex m; return m; }
+std::vector<const void *> &lds_reports() { static std::vector<const void *> v; return v; }
+// deliberately out of range through one of the checked helpers (the hardware drops the store): `floats` past the launch's LDS
+__global__ void lds_selftest_kernel(int floats, float *out) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  if (threadIdx.x == 0) {
+    st32_f4(lds, 0, make_float4(1.f, 2.f, 3.f, 4.f));                  // in range: not counted
+    st32_f4(lds, (unsigned)floats, make_float4(5.f, 6.f, 7.f, 8.f));   // [floats, floats + 4): counted once
+    out[0] = ld32_f4(lds, 0).y;
+  }
+}
+}  // namespace
+void lds_report_register(const void *symbol) {
+  std::lock_guard<std::mutex> hold(lds_reports_lock());
+  lds_reports().push_back(symbol);
+}
+}  // namespace dfgnn
+
+// out[0] = violations since the last call summed over the translation units (the counters are cleared), out[1..3] = source
+// line (dfgnn_dense*.hpp), end offset and limit of the first violation of the first unit that saw one.  Returns the number
+// of translation units compiled with the checks (0 would mean "not a checking build"), negative on a HIP error.
+extern "C" int dfgnn_debug_lds_report(unsigned *out) {
+  std::lock_guard<std::mutex> hold(dfgnn::lds_reports_lock());
+  unsigned total[4] = {0, 0, 0, 0};
+  const unsigned zero[4] = {0, 0, 0, 0};
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  for (const void *sym : dfgnn::lds_reports()) {
+    unsigned r[4];
+    if (hipMemcpyFromSymbol(r, sym, sizeof(r)) != hipSuccess) return -1;
+    if (r[0] && !total[0]) { total[1] = r[1]; total[2] = r[2]; total[3] = r[3]; }
+    total[0] += r[0];
+    if (hipMemcpyToSymbol(sym, zero, sizeof(zero)) != hipSuccess) return -1;
+  }
+  for (int k = 0; k < 4; ++k) out[k] = total[k];
+  return (int)dfgnn::lds_reports().size();
+}
+// One store 16 bytes past `lds_bytes` of dynamic LDS through st32_f4: the next report must show exactly one violation
+// with limit = lds_bytes.
+extern "C" int dfgnn_debug_lds_selftest(int lds_bytes, float *out, void *stream) {
+  dfgnn::lds_selftest_kernel<<<1, 64, lds_bytes, static_cast<hipStream_t>(stream)>>>(lds_bytes / 4, out);
+  return (int)hipGetLastError();
+}
+#endif

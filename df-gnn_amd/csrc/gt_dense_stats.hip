@@ -138,6 +138,7 @@ int launch_gt_dense_fwd_stats(const Csr &g_in, const Plan &p, const float *Q, co
   Csr g = g_in;
   g.mask = p.mask();
   g.maskT = p.maskT();
+  if (g.wdense) return launch_gt_dense_fwd_stats_w(g, p, Q, K, V, out, stat_max, stat_sum, s);  // edge values
   const dim3 grid(p.num_dense, 1);
   // a batch without ranges of more than 128 nodes: the 256-thread forward, two workgroups per CU (dfgnn_dense_lean.hpp)
   const bool lean = (g.f == 64 || g.f == 128) && g.h == 1 && p.num_dense_wide == 0 && stats_lean_enabled();
@@ -164,6 +165,7 @@ int launch_gt_dense_bwd_stats(const Csr &g_in, const Plan &p, const float *Q, co
   Csr g = g_in;
   g.mask = p.mask();
   g.maskT = p.maskT();
+  if (g.wdense) return launch_gt_dense_bwd_stats_w(g, p, Q, K, V, stat_max, stat_sum, grad_out, dQ, dK, dV, s);  // edge values
   const dim3 grid(p.num_dense, g.h);
   // multi-head: every head of a range of <= 160 nodes in one workgroup (dense_bwd_heads2_body) for heads of at most
   // kHeads2MaxF features; wider heads run per (range, head) on the single-head bodies

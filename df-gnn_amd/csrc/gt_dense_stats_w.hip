@@ -1,0 +1,107 @@
+// gt_dense_stats_w.hip -- the statistics-saving GT pair (gt_dense_stats.hip) for WEIGHTED edges: logit = (Q_i . K_j) val_ij,
+// the reference's `attn * val` (fused_gtconv_hyper.cu:88-90), on the matrix cores.
+//
+// The dense kernels know WHERE the edges are from the plan's bitmaps; what an edge value needs in addition is a place a
+// lane can fetch it from by (row, column) -- the CSR position of an edge is exactly what these kernels do not have.  So
+// the values are laid out once per (plan, val) in dense form, W[256 i + c] = val of the edge from node i to the c-th node
+// of its range (plan.hip: dfgnn_plan_dense_weights; 1 KB per node, of which a row touches its range's width), and a lane
+// reads the 4 values of a 16-column tile with one 16-byte load where the unit-value kernels read nothing:
+//   forward :  x_ij = S_ij W_ij on the bitmap's edges, then the softmax, statistics and P V product unchanged
+//   backward:  P recomputed from S W; dS_ij = P_ij (dP_ij - t_i) W_ij goes into the dQ and dK products (d x / d S = W)
+// One instance per shape: the range classes of the unit-value pair (<= 128, 129-160, > 160 nodes) per (range, head) --
+// the all-heads-in-one-workgroup bodies are not instantiated for weights.  Inference with weights runs the forward
+// without statistics (null pointers).
+#include <type_traits>
+
+#include "dfgnn_dense.hpp"
+#include "dfgnn_dense_stamp.hpp"
+#ifndef DFGNN_RING160
+#define DFGNN_RING160 2
+#endif
+#include "dfgnn_dense_wide.hpp"
+#include "dfgnn_dense_fwd.hpp"
+#include "dfgnn_dense_bwd.hpp"
+#include "dfgnn_dense_bwd_rc2.hpp"
+
+namespace dfgnn {
+
+// grid (dense ranges, heads)
+template <int F>
+__global__ __launch_bounds__(kDenseThreads) void gt_dense_fwd_stats_w_kernel(Csr g, const int *__restrict__ fit,
+                                                                             const float *__restrict__ Q,
+                                                                             const float *__restrict__ K,
+                                                                             const float *__restrict__ V,
+                                                                             float *__restrict__ out,
+                                                                             float *__restrict__ stat_max,
+                                                                             float *__restrict__ stat_sum, int lds_bytes) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int n0 = fit[2 * blockIdx.x], n1 = fit[2 * blockIdx.x + 1] & kPlanRangeMask;
+  const int n = n1 - n0, head = blockIdx.y;
+  if (n <= kDenseChunkRows)
+    dense_fwd_body<F, false, 1, kDenseChunkRows, 1, false, false, true, true>(lds, lds_bytes, g, n0, n, 0, 0, head, 1, Q, K, V,
+                                                                              nullptr, out, 0.f, stat_max, stat_sum);
+  else if (n <= kDenseWideRows)
+    dense_fwd_body<F, false, 2, kDenseWideRows, 1, false, false, true, true>(lds, lds_bytes, g, n0, n, 0, 0, head, 1, Q, K, V,
+                                                                             nullptr, out, 0.f, stat_max, stat_sum);
+  else
+    dense_fwd_body<F, false, 2, kDenseChunkRows, 2, false, false, true, true>(lds, lds_bytes, g, n0, n, 0, 0, head, 1, Q, K, V,
+                                                                              nullptr, out, 0.f, stat_max, stat_sum);
+}
+
+template <int F>
+__global__ __launch_bounds__(kDenseThreads) void gt_dense_bwd_stats_w_kernel(
+    Csr g, const int *__restrict__ fit, const float *__restrict__ Q, const float *__restrict__ K,
+    const float *__restrict__ V, const float *__restrict__ stat_max, const float *__restrict__ stat_sum,
+    const float *__restrict__ dO, float *__restrict__ dQ, float *__restrict__ dK, float *__restrict__ dV) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int range = blockIdx.x, head = blockIdx.y;
+  const int n0 = fit[2 * range], n1 = fit[2 * range + 1] & kPlanRangeMask;
+  const int n = n1 - n0;
+  GatBwdArgs st{};
+  st.edge_max = stat_max;
+  st.edge_sum = stat_sum;
+  if (n <= kDenseChunkRows)
+    dense_bwd_rc2_body<F, true>(lds, g, n0, n, head, Q, K, V, stat_max, stat_sum, dO, dQ, dK, dV);
+  else if (n <= kDenseWideRows)
+    dense_bwd_wide_body<F, kDenseWideRows, DFGNN_RING160, 64, true, true>(lds, g, n0, n, 0, 0, head, Q, K, V, nullptr, dO, dQ, dK,
+                                                                         dV, stat_max, stat_sum);
+  else
+    dense_bwd_body<F, kDenseChunkRows, 2, false, true, true>(lds, g, n0, n, 0, 0, head, Q, K, V, nullptr, dO, dQ, dK, dV, st);
+}
+
+template <class Fn>
+static int dispatch_dense_w(int f, Fn &&fn) {
+  if (f == 8) return fn(std::integral_constant<int, 8>{});  // f = 8 / 16: zero-padded onto the 32-wide layout
+  if (f == 16) return fn(std::integral_constant<int, 16>{});
+  if (f == 32) return fn(std::integral_constant<int, 32>{});
+  if (f == 64) return fn(std::integral_constant<int, 64>{});
+  if (f == 128) return fn(std::integral_constant<int, 128>{});
+  return kErrUnsupported;
+}
+
+// g.wdense, g.mask, g.maskT set by the caller (launch_gt_dense_fwd_stats / launch_gt_dense_bwd_stats)
+int launch_gt_dense_fwd_stats_w(const Csr &g, const Plan &p, const float *Q, const float *K, const float *V, float *out,
+                                float *stat_max, float *stat_sum, hipStream_t s) {
+  const dim3 grid(p.num_dense, g.h);
+  return dispatch_dense_w(g.f, [&](auto fc) {
+    constexpr int F = decltype(fc)::value;
+    if (int rc = set_max_lds_cached(gt_dense_fwd_stats_w_kernel<F>)) return rc;
+    gt_dense_fwd_stats_w_kernel<F><<<grid, kDenseThreads, kLdsBytes, s>>>(g, p.fit(), Q, K, V, out, stat_max, stat_sum, kLdsBytes);
+    return launch_status();
+  });
+}
+
+int launch_gt_dense_bwd_stats_w(const Csr &g, const Plan &p, const float *Q, const float *K, const float *V,
+                                const float *stat_max, const float *stat_sum, const float *grad_out, float *dQ, float *dK,
+                                float *dV, hipStream_t s) {
+  const dim3 grid(p.num_dense, g.h);
+  return dispatch_dense_w(g.f, [&](auto fc) {
+    constexpr int F = decltype(fc)::value;
+    if (int rc = set_max_lds_cached(gt_dense_bwd_stats_w_kernel<F>)) return rc;
+    gt_dense_bwd_stats_w_kernel<F><<<grid, kDenseThreads, kLdsBytes, s>>>(g, p.fit(), Q, K, V, stat_max, stat_sum, grad_out, dQ,
+                                                                          dK, dV);
+    return launch_status();
+  });
+}
+
+}  // namespace dfgnn

@@ -413,6 +413,23 @@ __global__ __launch_bounds__(256) void plan_coords_kernel(const int *__restrict_
   }
 }
 
+// Edge values of the dense ranges in dense form: W[256 i + c] = val[e] for the edge e from node i to the node c places
+// after the first node of i's range (coords[e] holds (r, c)); the buffer was zeroed before.  One workgroup per range walk.
+__global__ __launch_bounds__(256) void plan_dense_weights_kernel(const int *__restrict__ row_ptr, const int *plan,
+                                                                 const unsigned short *__restrict__ coords,
+                                                                 const float *__restrict__ val, float *__restrict__ W) {
+  const int ndense = plan[9];
+  const int *fit = plan + kPlanHeader;
+  for (int k = blockIdx.x; k < ndense; k += gridDim.x) {
+    const int n0 = fit[2 * k], n1 = fit[2 * k + 1] & kPlanRangeMask;
+    const int ea = row_ptr[n0], eb = row_ptr[n1];
+    for (int e = ea + (int)threadIdx.x; e < eb; e += 256) {
+      const unsigned c = coords[e];
+      W[(size_t)(n0 + (int)(c >> 8)) * kPlanWeightStride + (c & 0xFFu)] = val[e];
+    }
+  }
+}
+
 }  // namespace dfgnn
 
 using namespace dfgnn;
@@ -485,6 +502,24 @@ int dfgnn_plan_build(int m, int nnz, int f, const int *row_ptr, const int *col_i
   }
   if (hipError_t rc = hipMemcpyAsync(meta_host, plan, kPlanHeader * sizeof(int), hipMemcpyDeviceToHost, s)) return (int)rc;
   return (int)hipStreamSynchronize(s);
+}
+
+// Dense edge values for the WEIGHTED statistics pair (dfgnn.h): weights[256 m] floats, zero off the edges.
+size_t dfgnn_plan_dense_weights_floats(int m) { return m < 0 ? 0 : (size_t)kPlanWeightStride * (size_t)m; }
+
+int dfgnn_plan_dense_weights(int m, int nnz, const int *row_ptr, const float *val, const int *plan, const int *plan_meta,
+                             float *weights, dfgnn_stream_t stream) {
+  if (m < 0 || nnz < 0 || !plan || !plan_meta) return kErrBadArg;
+  if (m == 0) return 0;
+  if (!row_ptr || !weights || (nnz > 0 && !val)) return kErrBadArg;
+  if (plan_meta[4] != m || plan_meta[5] != nnz) return kErrBadArg;  // a plan of another graph
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (hipError_t rc = hipMemsetAsync(weights, 0, dfgnn_plan_dense_weights_floats(m) * sizeof(float), s)) return (int)rc;
+  if (nnz == 0 || plan_meta[9] == 0) return 0;
+  const size_t coords_off = plan_coords_off(m);
+  plan_dense_weights_kernel<<<(unsigned)min(plan_meta[9], 4096), 256, 0, s>>>(
+      row_ptr, plan, reinterpret_cast<const unsigned short *>(plan + coords_off), val, weights);
+  return launch_status();
 }
 
 }  // extern "C"

@@ -148,24 +148,44 @@ GtDims gt_stats_checks(const Tensor &row_ptr, const Tensor &col_ind, const Tenso
   return GtDims{(int)Q.size(0), (int)col_ind.size(0), (int)Q.size(1), (int)Q.size(2)};
 }
 
+// weights: the plan's dense edge values (plan_dense_weights below), or nothing for unit values
+const float *weights_ptr(const c10::optional<Tensor> &weights, const Tensor &Q, int m) {
+  if (!weights.has_value()) return nullptr;
+  const Tensor &w = *weights;
+  check_f32(w, "weights");
+  TORCH_CHECK(w.numel() == (int64_t)dfgnn_plan_dense_weights_floats(m), "weights must hold ", dfgnn_plan_dense_weights_floats(m),
+              " floats (dfgnn_plan_dense_weights), got ", w.numel());
+  TORCH_CHECK(w.device() == Q.device(), "weights must live on the device of Q");
+  return w.data_ptr<float>();
+}
+
+// save_stats = false: inference (nothing but `out` is produced; edge values on the matrix cores)
 std::vector<Tensor> gt_hyper_fwd_stats(const Tensor &row_ptr, const Tensor &col_ind, const Tensor &Q, const Tensor &K,
-                                       const Tensor &V, int64_t plan, int64_t meta) {
+                                       const Tensor &V, int64_t plan, int64_t meta, const c10::optional<Tensor> &weights,
+                                       bool save_stats) {
   const GtDims d = gt_stats_checks(row_ptr, col_ind, Q, K, V);
+  const float *w = weights_ptr(weights, Q, d.m);
   c10::hip::HIPGuardMasqueradingAsCUDA guard(Q.device());
   Tensor out = torch::empty_like(Q);
-  Tensor row_max = torch::empty({d.m, d.h}, Q.options()), row_sum = torch::empty({d.m, d.h}, Q.options());
-  check_rc(dfgnn_gt_hyper_fwd_stats(d.m, d.nnz, d.h, d.f, row_ptr.data_ptr<int>(), col_ind.data_ptr<int>(), Q.data_ptr<float>(),
-                                    K.data_ptr<float>(), V.data_ptr<float>(), row_max.data_ptr<float>(),
-                                    row_sum.data_ptr<float>(), out.data_ptr<float>(), plan_ptr(plan), plan_ptr(meta),
-                                    cur_stream()),
+  Tensor row_max, row_sum;
+  if (save_stats) {
+    row_max = torch::empty({d.m, d.h}, Q.options());
+    row_sum = torch::empty({d.m, d.h}, Q.options());
+  }
+  check_rc(dfgnn_gt_hyper_fwd_stats(d.m, d.nnz, d.h, d.f, row_ptr.data_ptr<int>(), col_ind.data_ptr<int>(), w, Q.data_ptr<float>(),
+                                    K.data_ptr<float>(), V.data_ptr<float>(), save_stats ? row_max.data_ptr<float>() : nullptr,
+                                    save_stats ? row_sum.data_ptr<float>() : nullptr, out.data_ptr<float>(), plan_ptr(plan),
+                                    plan_ptr(meta), cur_stream()),
            "gt_hyper_forward_stats");
+  if (!save_stats) return {out};
   return {out, row_max, row_sum};
 }
 
 std::vector<Tensor> gt_bwd_stats(const Tensor &row_ptr, const Tensor &col_ind, const Tensor &Q, const Tensor &K,
                                  const Tensor &V, const Tensor &row_max, const Tensor &row_sum, const Tensor &grad,
-                                 int64_t plan, int64_t meta) {
+                                 int64_t plan, int64_t meta, const c10::optional<Tensor> &weights) {
   const GtDims d = gt_stats_checks(row_ptr, col_ind, Q, K, V);
+  const float *w = weights_ptr(weights, Q, d.m);
   check_feat3(grad, Q, "grad");
   check_f32(row_max, "row_max");
   check_f32(row_sum, "row_sum");
@@ -177,12 +197,27 @@ std::vector<Tensor> gt_bwd_stats(const Tensor &row_ptr, const Tensor &col_ind, c
   TORCH_CHECK(grad.device() == Q.device(), "grad must live on the device of Q");
   c10::hip::HIPGuardMasqueradingAsCUDA guard(Q.device());
   Tensor dQ = torch::empty_like(Q), dK = torch::empty_like(K), dV = torch::empty_like(V);
-  check_rc(dfgnn_gt_bwd_stats(d.m, d.nnz, d.h, d.f, row_ptr.data_ptr<int>(), col_ind.data_ptr<int>(), Q.data_ptr<float>(),
+  check_rc(dfgnn_gt_bwd_stats(d.m, d.nnz, d.h, d.f, row_ptr.data_ptr<int>(), col_ind.data_ptr<int>(), w, Q.data_ptr<float>(),
                               K.data_ptr<float>(), V.data_ptr<float>(), row_max.data_ptr<float>(), row_sum.data_ptr<float>(),
                               grad.data_ptr<float>(), dQ.data_ptr<float>(), dK.data_ptr<float>(), dV.data_ptr<float>(),
                               plan_ptr(plan), plan_ptr(meta), cur_stream()),
            "gt_backward_stats");
   return {dQ, dK, dV};
+}
+
+// the edge values of a plan's dense ranges in dense form (dfgnn_plan_dense_weights): fp32[256 m]
+Tensor plan_dense_weights(const Tensor &row_ptr, const Tensor &val, int64_t plan, int64_t meta) {
+  check_i32(row_ptr, "row_ptr");
+  check_f32(val, "val");
+  TORCH_CHECK(row_ptr.dim() == 1 && row_ptr.size(0) >= 1, "indptr must be 1-D");
+  TORCH_CHECK(val.device() == row_ptr.device(), "val must live on the device of indptr");
+  const int m = (int)row_ptr.size(0) - 1, nnz = (int)val.numel();
+  c10::hip::HIPGuardMasqueradingAsCUDA guard(row_ptr.device());
+  Tensor w = torch::empty({(int64_t)dfgnn_plan_dense_weights_floats(m)}, val.options());
+  check_rc(dfgnn_plan_dense_weights(m, nnz, row_ptr.data_ptr<int>(), val.data_ptr<float>(), plan_ptr(plan), plan_ptr(meta),
+                                    w.data_ptr<float>(), cur_stream()),
+           "plan_dense_weights");
+  return w;
 }
 
 struct GatDims {
@@ -424,6 +459,7 @@ PYBIND11_MODULE(_dfgnn_ext, m) {
   m.def("gt_bwd", &gt_bwd, "fused GT conv backward");
   m.def("gt_hyper_fwd_stats", &gt_hyper_fwd_stats, "fused GT conv 'hyper' training forward, row statistics instead of attn_edge");
   m.def("gt_bwd_stats", &gt_bwd_stats, "fused GT conv backward from the row statistics");
+  m.def("plan_dense_weights", &plan_dense_weights, "edge values of a plan's dense ranges in dense form (dfgnn_plan_dense_weights)");
   m.def("gat_hyper_fwd", &gat_hyper_fwd, "fused GAT conv 'hyper' inference");
   m.def("gat_softmax_fwd", &gat_softmax_fwd, "fused GAT conv 'softmax' / 'softmax_gm' inference");
   m.def("gat_tiling_fwd", &gat_tiling_fwd, "fused GAT conv 'tiling' inference");

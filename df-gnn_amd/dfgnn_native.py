@@ -23,8 +23,9 @@ SIGNATURES = {
     "dfgnn_gt_hyper_fwd": [_i, _i, _i, _i] + [_vp] * 13,
     "dfgnn_gt_bwd": [_i, _i, _i, _i] + [_vp] * 19,
     "dfgnn_gt_stats_applies": [_i, _i, _i, _i, _vp],
-    "dfgnn_gt_hyper_fwd_stats": [_i, _i, _i, _i] + [_vp] * 11,
-    "dfgnn_gt_bwd_stats": [_i, _i, _i, _i] + [_vp] * 14,
+    "dfgnn_gt_hyper_fwd_stats": [_i, _i, _i, _i] + [_vp] * 12,
+    "dfgnn_gt_bwd_stats": [_i, _i, _i, _i] + [_vp] * 15,
+    "dfgnn_plan_dense_weights": [_i, _i] + [_vp] * 6,
     "dfgnn_gt_bwd_rows": [_i, _i, _i, _i] + [_vp] * 11,
     "dfgnn_gt_bwd_cols": [_i, _i, _i, _i] + [_vp] * 11,
     "dfgnn_gt_tiling_fwd": [_i, _i, _i, _i] + [_vp] * 8,
@@ -107,6 +108,8 @@ def lib():
         L.dfgnn_plan_ints.restype = ctypes.c_size_t
         L.dfgnn_plan_applies.argtypes = [ctypes.c_int] * 4 + [ctypes.c_void_p]
         L.dfgnn_plan_applies.restype = ctypes.c_int
+        L.dfgnn_plan_dense_weights_floats.argtypes = [ctypes.c_int]
+        L.dfgnn_plan_dense_weights_floats.restype = ctypes.c_size_t
         L.dfgnn_preprocess_ws_bytes.argtypes = [ctypes.c_int, ctypes.c_int]
         L.dfgnn_preprocess_ws_bytes.restype = ctypes.c_size_t
         L.dfgnn_gat_tiling_chunked_ws_bytes.argtypes = [ctypes.c_int] * 4

@@ -15,7 +15,8 @@ import torch
 import dfgnn_native as _n
 import os
 
-from _binding_util import (as_int32, check_contiguous, check_device, check_dtype, check_feat3, get_plan, get_plan_obj, ptr,
+from _binding_util import (as_int32, check_contiguous, check_device, check_dtype, check_feat3, get_plan, get_plan_obj,
+                           plan_dense_weights, ptr,
                            stream_ptr, val_ptr)
 
 # Set to False to force the general (plan-less) kernels; results are identical either way.
@@ -48,6 +49,12 @@ def _check_edges(nnz, **arrs):
 
 def gt_hyper_inference(indptr, indices, rows, val, smem_consume, Q, K, V):
     """fused_gtconv.cpp:278-314 -> [out]"""
+    if val_ptr(val) is not None and Q.dim() == 3 and Q.is_cuda:
+        # edge values: the matrix-core forward reads them in the plan's dense form (csrc/gt_dense_stats_w.hip) when
+        # every range of the batch is dense; anything else takes the edge-walking kernels below
+        plan = gt_stats_pair_applies(indptr, indices, val, Q)
+        if plan is not None:
+            return gt_hyper_forward_stats(indptr, indices, Q, K, V, plan=plan, val=val, save_stats=False)
     ext = _n.ext()
     if ext is not None:  # torch C++ binding (csrc/torch_ext.cpp): same checks, same C ABI call
         plan, meta, _ = get_plan(indptr, indices, Q.size(-1) if Q.dim() == 3 else 0, USE_BLOCK_PLAN)
@@ -139,46 +146,65 @@ def gt_backward(row_ptr, col_ind, rows, val, col_ptr, row_ind, val_idx, smem_con
 # ---- the statistics-saving training pair (include/dfgnn.h: dfgnn_gt_hyper_fwd_stats / dfgnn_gt_bwd_stats) ------------
 # Not part of the reference's module: FusedGTFunction_hyper (DFGNN/operators/fused_gtconv.py) takes this pair instead of
 # gt_hyper_forward / gt_backward when the whole batch runs on the matrix-core kernels -- same results, no attn_edge.
-# DFGNN_STATS=0 in the environment keeps the attn_edge pair everywhere (A/B runs).
-USE_STATS_PAIR = os.environ.get("DFGNN_STATS", "1") != "0"
+# Which pair the autograd Function takes is a measured choice: the statistics pair saves the attn_edge
+# round trip (8 h nnz bytes) and pays one more K image pass in the backward -- from two heads on it is the faster one
+# (8 x 16 heads: 0.58 against 0.65 ms per step), at one head the attn_edge pair is (0.263 against 0.267 ms).
+# DFGNN_STATS in the environment: 0 = the attn_edge pair everywhere, 1 = the statistics pair wherever it applies (A/B runs).
+_STATS_ENV = os.environ.get("DFGNN_STATS", "auto")
+USE_STATS_PAIR = _STATS_ENV != "0"
+STATS_PAIR_MIN_HEADS = 1 if _STATS_ENV == "1" else 2
 
 
 def gt_stats_pair_applies(row_ptr, col_ind, val, Q):
-    """The block plan (a true value) when gt_hyper_forward_stats / gt_backward_stats can serve this call -- unit edge
-    values and a plan whose ranges are all dense (dfgnn_gt_stats_applies) -- else None.  The plan may be handed to the two
-    calls (`plan=`), which then skip their own look-up."""
+    """The block plan (a true value) when gt_hyper_forward_stats / gt_backward_stats can serve this call -- a plan whose
+    ranges are all dense (dfgnn_gt_stats_applies) -- else None.  The plan may be handed to the two calls (`plan=`), which
+    then skip their own look-up; edge values other than ones go along as `val=` (the calls turn them into the plan's
+    dense weights, _binding_util.plan_dense_weights)."""
     if not (USE_STATS_PAIR and USE_BLOCK_PLAN) or Q.dim() != 3 or not Q.is_cuda:
         return None
     plan = get_plan_obj(row_ptr, col_ind, Q.size(-1), True)
-    if plan is not None and plan.stats_applies(Q.size(1)) and val_ptr(val) is None:
+    if plan is not None and plan.stats_applies(Q.size(1)):
         return plan
     return None
 
 
-def _plan_ptrs(plan, row_ptr, col_ind, Q):
-    if plan is not None:
-        return plan.ptrs()
-    p, m, _ = get_plan(row_ptr, col_ind, Q.size(-1) if Q.dim() == 3 else 0, USE_BLOCK_PLAN)
-    return p, m
+def gt_stats_pair_chosen(row_ptr, col_ind, val, Q):
+    """gt_stats_pair_applies under the policy above: the plan when the autograd Function should take the statistics pair
+    for this call, else None.  With edge values it is always the pair to take where it applies: the attn_edge pair has
+    no matrix-core form for them."""
+    if Q.dim() != 3 or (Q.size(1) < STATS_PAIR_MIN_HEADS and val_ptr(val) is None):
+        return None
+    return gt_stats_pair_applies(row_ptr, col_ind, val, Q)
+
+
+def _stats_weights(plan, row_ptr, val):
+    """None for unit edge values (or no `val`), else the plan's dense weights of `val`."""
+    if val is None or val_ptr(val) is None:
+        return None
+    return plan_dense_weights(plan, row_ptr, val)
 
 
 def gt_hyper_step_raw(row_ptr, col_ind, rows, val, col_ptr, row_ind, val_idx, smem, Q, K, V, grad):
     """-> [out, dQ, dK, dV]: the launches of one FusedGTFunction_hyper forward + backward as explicit operator calls (no
     autograd graph), choosing the pair the way the autograd function does -- what the HIP-graph replays capture."""
-    plan = gt_stats_pair_applies(row_ptr, col_ind, val, Q)
+    plan = gt_stats_pair_chosen(row_ptr, col_ind, val, Q)
     if plan is not None:
-        out, rmax, rsum = gt_hyper_forward_stats(row_ptr, col_ind, Q, K, V, plan=plan)
-        return [out] + list(gt_backward_stats(row_ptr, col_ind, Q, K, V, rmax, rsum, grad, plan=plan))
+        out, rmax, rsum = gt_hyper_forward_stats(row_ptr, col_ind, Q, K, V, plan=plan, val=val)
+        return [out] + list(gt_backward_stats(row_ptr, col_ind, Q, K, V, rmax, rsum, grad, plan=plan, val=val))
     out, attn = gt_hyper_forward(row_ptr, col_ind, rows, val, col_ptr, row_ind, val_idx, smem, Q, K, V)
     return [out] + list(gt_backward(row_ptr, col_ind, rows, val, col_ptr, row_ind, val_idx, smem, Q, K, V, attn, grad))
 
 
-def gt_hyper_forward_stats(row_ptr, col_ind, Q, K, V, plan=None):
-    """-> [out, row_max[m, h], row_sum[m, h]]: the training forward without attn_edge (call gt_stats_pair_applies first)."""
+def gt_hyper_forward_stats(row_ptr, col_ind, Q, K, V, plan=None, val=None, save_stats=True):
+    """-> [out, row_max[m, h], row_sum[m, h]]: the training forward without attn_edge (call gt_stats_pair_applies first).
+    val: edge values (None or all ones: unit values).  save_stats=False -> [out] (inference)."""
     ext = _n.ext()
-    plan, meta = _plan_ptrs(plan, row_ptr, col_ind, Q)
+    if plan is None:
+        plan = get_plan_obj(row_ptr, col_ind, Q.size(-1) if Q.dim() == 3 else 0, USE_BLOCK_PLAN)
+    weights = _stats_weights(plan, row_ptr, val) if plan is not None else None
+    plan, meta = plan.ptrs() if plan is not None else (None, None)
     if ext is not None and hasattr(ext, "gt_hyper_fwd_stats"):
-        return ext.gt_hyper_fwd_stats(row_ptr, col_ind, Q, K, V, plan or 0, meta or 0)
+        return ext.gt_hyper_fwd_stats(row_ptr, col_ind, Q, K, V, plan or 0, meta or 0, weights, save_stats)
     check_device(row_ptr=row_ptr, col_ind=col_ind)
     check_contiguous(row_ptr=row_ptr, col_ind=col_ind)
     check_dtype(torch.int32, row_ptr=row_ptr, col_ind=col_ind)
@@ -187,20 +213,23 @@ def gt_hyper_forward_stats(row_ptr, col_ind, Q, K, V, plan=None):
     _check_graph(row_ptr, col_ind, Q.size(0))
     with torch.cuda.device(Q.device):
         out = torch.empty_like(Q)
-        row_max = torch.empty((m, h), dtype=torch.float32, device=Q.device)
-        row_sum = torch.empty((m, h), dtype=torch.float32, device=Q.device)
-        _n.check(_n.lib().dfgnn_gt_hyper_fwd_stats(m, nnz, h, f, ptr(row_ptr), ptr(col_ind), ptr(Q), ptr(K), ptr(V),
-                                                   ptr(row_max), ptr(row_sum), ptr(out), plan, meta,
+        row_max = torch.empty((m, h), dtype=torch.float32, device=Q.device) if save_stats else None
+        row_sum = torch.empty((m, h), dtype=torch.float32, device=Q.device) if save_stats else None
+        _n.check(_n.lib().dfgnn_gt_hyper_fwd_stats(m, nnz, h, f, ptr(row_ptr), ptr(col_ind), ptr(weights), ptr(Q), ptr(K),
+                                                   ptr(V), ptr(row_max), ptr(row_sum), ptr(out), plan, meta,
                                                    stream_ptr(Q.device)), "gt_hyper_forward_stats")
-    return [out, row_max, row_sum]
+    return [out, row_max, row_sum] if save_stats else [out]
 
 
-def gt_backward_stats(row_ptr, col_ind, Q, K, V, row_max, row_sum, grad, plan=None):
+def gt_backward_stats(row_ptr, col_ind, Q, K, V, row_max, row_sum, grad, plan=None, val=None):
     """-> [dQ, dK, dV] from the row statistics of gt_hyper_forward_stats (P is recomputed on the matrix cores)."""
     ext = _n.ext()
-    plan, meta = _plan_ptrs(plan, row_ptr, col_ind, Q)
+    if plan is None:
+        plan = get_plan_obj(row_ptr, col_ind, Q.size(-1) if Q.dim() == 3 else 0, USE_BLOCK_PLAN)
+    weights = _stats_weights(plan, row_ptr, val) if plan is not None else None
+    plan, meta = plan.ptrs() if plan is not None else (None, None)
     if ext is not None and hasattr(ext, "gt_bwd_stats"):
-        return ext.gt_bwd_stats(row_ptr, col_ind, Q, K, V, row_max, row_sum, grad, plan or 0, meta or 0)
+        return ext.gt_bwd_stats(row_ptr, col_ind, Q, K, V, row_max, row_sum, grad, plan or 0, meta or 0, weights)
     check_device(row_ptr=row_ptr, col_ind=col_ind, row_max=row_max, row_sum=row_sum, grad=grad)
     check_contiguous(row_ptr=row_ptr, col_ind=col_ind, row_max=row_max, row_sum=row_sum, grad=grad)
     check_dtype(torch.int32, row_ptr=row_ptr, col_ind=col_ind)
@@ -214,8 +243,8 @@ def gt_backward_stats(row_ptr, col_ind, Q, K, V, row_max, row_sum, grad, plan=No
             raise RuntimeError(f"{name} must have shape ({m}, {h}), got {tuple(t.shape)}")
     with torch.cuda.device(Q.device):
         dQ, dK, dV = torch.empty_like(Q), torch.empty_like(K), torch.empty_like(V)
-        _n.check(_n.lib().dfgnn_gt_bwd_stats(m, nnz, h, f, ptr(row_ptr), ptr(col_ind), ptr(Q), ptr(K), ptr(V), ptr(row_max),
-                                             ptr(row_sum), ptr(grad), ptr(dQ), ptr(dK), ptr(dV), plan, meta,
+        _n.check(_n.lib().dfgnn_gt_bwd_stats(m, nnz, h, f, ptr(row_ptr), ptr(col_ind), ptr(weights), ptr(Q), ptr(K), ptr(V),
+                                             ptr(row_max), ptr(row_sum), ptr(grad), ptr(dQ), ptr(dK), ptr(dV), plan, meta,
                                              stream_ptr(Q.device)), "gt_backward_stats")
     return [dQ, dK, dV]
 

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define DFGNN_ABI_VERSION 9
+#define DFGNN_ABI_VERSION 10
 
 #define DFGNN_E_BADARG (-1)      /* negative size / NULL required pointer                      */
 #define DFGNN_E_UNSUPPORTED (-2) /* feature width outside the compiled range (f > 1024, or     */
@@ -127,19 +127,30 @@ int dfgnn_gt_bwd(int m, int nnz, int h, int f, const int *row_ptr, const int *co
  * fused_gtconv_backward.cu:132-136: 8 h nnz bytes through HBM) the forward saves, per (row, head), the logit maximum and
  * the sum of exponentials -- row_max, row_sum: fp32[m, h]; an empty row has row_max = -1e38, row_sum = 0 -- and the
  * backward recomputes P_e = exp(s_e - row_max) / row_sum with one more Q K^T product on the matrix cores.
- * Unit edge values only (there is no `val`), and only for batches that the matrix-core kernels cover completely:
- * dfgnn_gt_stats_applies(m, nnz, h, f, plan_meta) == 1 (host-only; every range of the plan dense, nothing spilled);
- * otherwise both calls return DFGNN_E_UNSUPPORTED and the caller uses dfgnn_gt_hyper_fwd / dfgnn_gt_bwd.  The sparse
- * structure reaches these kernels through the plan's edge bitmaps alone: rows, CSC arrays, grad_edge are not needed.
+ * Only for batches that the matrix-core kernels cover completely: dfgnn_gt_stats_applies(m, nnz, h, f, plan_meta) == 1
+ * (host-only; every range of the plan dense, nothing spilled); otherwise both calls return DFGNN_E_UNSUPPORTED and the
+ * caller uses dfgnn_gt_hyper_fwd / dfgnn_gt_bwd.  The sparse structure reaches these kernels through the plan's edge
+ * bitmaps alone: rows, CSC arrays, grad_edge are not needed.
+ * Edge values (the reference's `attn * val`, fused_gtconv_hyper.cu:88-90): `weights` = NULL for unit values, else the
+ * values in the dense form of dfgnn_plan_dense_weights below (built once per (plan, val), e.g. per batch of a dataset
+ * whose edge weights do not change): s_e = val_e <Q_i, K_j> in the forward, d s_e / d <Q_i, K_j> = val_e in the backward.
+ * row_max = row_sum = NULL in the forward: nothing is saved (inference with edge values on the matrix cores).
  * Results equal the attn_edge form's (same arithmetic for out; dQ, dK, dV to fp32 rounding). */
 int dfgnn_gt_stats_applies(int m, int nnz, int h, int f, const int *plan_meta);
-int dfgnn_gt_hyper_fwd_stats(int m, int nnz, int h, int f, const int *row_ptr, const int *col_ind, const float *Q,
-                             const float *K, const float *V, float *row_max, float *row_sum, float *out,
+int dfgnn_gt_hyper_fwd_stats(int m, int nnz, int h, int f, const int *row_ptr, const int *col_ind, const float *weights,
+                             const float *Q, const float *K, const float *V, float *row_max, float *row_sum, float *out,
                              const int *plan, const int *plan_meta, dfgnn_stream_t stream);
-int dfgnn_gt_bwd_stats(int m, int nnz, int h, int f, const int *row_ptr, const int *col_ind, const float *Q,
-                       const float *K, const float *V, const float *row_max, const float *row_sum,
+int dfgnn_gt_bwd_stats(int m, int nnz, int h, int f, const int *row_ptr, const int *col_ind, const float *weights,
+                       const float *Q, const float *K, const float *V, const float *row_max, const float *row_sum,
                        const float *grad_out, float *dQ, float *dK, float *dV, const int *plan, const int *plan_meta,
                        dfgnn_stream_t stream);
+/* weights[256 i + c] = val[e] for the edge e from node i to the c-th node of i's range of the plan, 0 elsewhere:
+ * dfgnn_plan_dense_weights_floats(m) = 256 m floats (device, 16-byte aligned), written by one memset + one kernel on
+ * `stream`.  val: fp32[nnz] in CSR order.  Only the dense ranges of the plan are filled (dfgnn_gt_stats_applies == 1:
+ * all of them). */
+size_t dfgnn_plan_dense_weights_floats(int m);
+int dfgnn_plan_dense_weights(int m, int nnz, const int *row_ptr, const float *val, const int *plan, const int *plan_meta,
+                             float *weights, dfgnn_stream_t stream);
 
 /* The two launches of the plan-less dfgnn_gt_bwd, exposed separately so each can be timed / profiled on its own
  * (dfgnn_gt_bwd == rows pass then cols pass on the same stream):

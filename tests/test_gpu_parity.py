@@ -531,7 +531,8 @@ def test_block_plan_structure():
 def test_block_kernels_match_oracle_and_general_path(oracle_mod, h, f, bs, unit_val):
     """'hyper' with the block plan (K/V resident in LDS) vs the oracle and vs the plan-less kernels.
     unit_val: all-ones edge values reach the C ABI as NULL and take the one-pass forward (K and V resident
-    together); weighted edges take the two-pass forward."""
+    together); weighted edges take the two-pass forward -- or, for inference on an all-dense batch, the matrix-core
+    forward with the values in the plan's dense form."""
     import fused_gtconv as gt
     from DFGNN.layers import preprocess_Hyper_fw_bw
     from DFGNN.utils import synthetic as S
@@ -549,6 +550,10 @@ def test_block_kernels_match_oracle_and_general_path(oracle_mod, h, f, bs, unit_
         out_p = gt.gt_hyper_inference(row_ptr, col_ind, rows, val, smem, Q, K, V)[0]
         out_t, attn_t = gt.gt_hyper_forward(row_ptr, col_ind, rows, val, col_ptr, row_ind, val_idx, smem, Q, K, V)
         assert row_ptr._dfgnn_plans[f].num_fit > 0
+        if f in (16, 32, 64, 128):   # widths with a matrix-core form: the ranges are dense, and the inference above ran on
+            # the matrix cores with or without edge values (weights in the plan's dense form, csrc/gt_dense_stats_w.hip)
+            assert row_ptr._dfgnn_plans[f].num_dense > 0
+            assert gt.gt_stats_pair_applies(row_ptr, col_ind, val, Q) is not None
         gt.USE_BLOCK_PLAN = False
         out_g = gt.gt_hyper_inference(row_ptr, col_ind, rows, val, smem, Q, K, V)[0]
     finally:

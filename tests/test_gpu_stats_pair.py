@@ -92,6 +92,52 @@ def test_stats_pair_every_geometry(oracle_mod, h, f):
         assert torch.allclose(a, b, atol=2e-5, rtol=1e-4), what
 
 
+@pytest.mark.parametrize("h,f", [(1, 128), (1, 64), (2, 64), (4, 32), (8, 16), (3, 32), (2, 8), (2, 128)])
+def test_weighted_edges_on_the_matrix_cores(oracle_mod, h, f):
+    """Edge values other than ones (the reference's `attn * val`, fused_gtconv_hyper.cu:88-90): the statistics pair reads
+    them in the plan's dense form (csrc/gt_dense_stats_w.hip) -- forward, inference and backward against the oracle on
+    every range class, positive and negative values, and the dense form itself against the CSR arrays."""
+    import fused_gtconv as gt
+    from _binding_util import get_plan_obj, plan_dense_weights, val_ptr
+    from DFGNN.layers import preprocess_Hyper_fw_bw
+    from DFGNN.utils import synthetic as S
+    g = _geometry_batch(29 + f)
+    A, rows, row_ptr, col_ind, val, col_ptr, row_ind, val_idx, smem = preprocess_Hyper_fw_bw(g)
+    m, nnz = g.num_nodes(), g.num_edges()
+    val = (torch.rand(nnz, 1, generator=torch.Generator().manual_seed(f)) * 2.5 - 1.0).to(DEV)   # in [-1, 1.5)
+    assert val_ptr(val) is not None
+    Q, K, V = S.gt_features(m, h, f, seed=5, device=DEV)
+    dO = torch.randn(m, h, f, generator=torch.Generator().manual_seed(3)).to(DEV)
+    plan = gt.gt_stats_pair_applies(row_ptr, col_ind, val, Q)
+    assert plan is not None and plan.num_dense == plan.num_fit > 0 and gt.gt_stats_pair_chosen(row_ptr, col_ind, val, Q) is plan
+    n_ = lambda t: t.cpu().numpy()  # noqa: E731
+    # the dense form: W[256 i + (j - n0)] = val[e], zero elsewhere
+    W = n_(plan_dense_weights(plan, row_ptr, val)).reshape(m, 256)
+    rp, ci, vv = n_(row_ptr), n_(col_ind), n_(val).reshape(-1)
+    fit = n_(plan.buf)[12:12 + 2 * plan.num_fit].reshape(-1, 2)
+    want_w = np.zeros((m, 256), np.float32)
+    for n0, n1f in fit:
+        for i in range(n0, n1f & ~((1 << 30) | (1 << 29))):
+            want_w[i, ci[rp[i]:rp[i + 1]] - n0] = vv[rp[i]:rp[i + 1]]
+    assert (W == want_w).all()
+    out, mx, sm = gt.gt_hyper_forward_stats(row_ptr, col_ind, Q, K, V, plan=plan, val=val)
+    dQ, dK, dV = gt.gt_backward_stats(row_ptr, col_ind, Q, K, V, mx, sm, dO, plan=plan, val=val)
+    (out_inf,) = gt.gt_hyper_inference(row_ptr, col_ind, rows, val, smem, Q, K, V)
+    want = oracle_mod.gt_forward(rp, ci, n_(val), n_(Q), n_(K), n_(V))
+    wq, wk, wv = oracle_mod.gt_backward(rp, ci, n_(val), n_(Q), n_(K), n_(V), n_(dO))
+    _close(out, want, "out")
+    assert torch.equal(out_inf, out)                       # the same kernel without the statistics
+    _close(dQ, wq, "dQ")
+    _close(dK, wk, "dK")
+    _close(dV, wv, "dV")
+    # the edge-walking kernels (what weighted edges took before) on the same inputs
+    args = (row_ptr, col_ind, rows, val, col_ptr, row_ind, val_idx, smem, Q, K, V)
+    out_a, attn = gt.gt_hyper_forward(*args)
+    dQ_a, dK_a, dV_a = gt.gt_backward(*args, attn, dO)
+    for a, b, what in ((out, out_a, "out"), (dQ, dQ_a, "dQ"), (dK, dK_a, "dK"), (dV, dV_a, "dV")):
+        assert torch.allclose(a, b, atol=5e-5, rtol=2e-4), what
+
+
 def test_plan_edge_bitmaps_equal_the_adjacency():
     """plan.hip: bit c of mask[8 i ..] <=> edge (i, n0 + c); bit r of maskT[8 j ..] <=> edge (n0 + r, j) -- for every
     node of every dense range, including the directed graphs (mask != maskT) and the isolated nodes (all zero)."""
@@ -128,24 +174,24 @@ def test_plan_edge_bitmaps_equal_the_adjacency():
 
 
 def test_autograd_function_takes_the_stats_pair_when_it_applies(oracle_mod, monkeypatch):
-    """FusedGTFunction_hyper: the statistics pair on an all-dense batch with unit edge values, the attn_edge pair when
-    one range is not dense (a duplicate edge), when the edge values are not all ones, and under DFGNN_STATS=0 -- with
-    the same gradients every time."""
+    """FusedGTFunction_hyper: the statistics pair on an all-dense batch with several heads or with edge values other than
+    ones, the attn_edge pair when one range is not dense (a duplicate edge), at one head with unit values (unless
+    DFGNN_STATS=1) and under DFGNN_STATS=0 -- with the same gradients every time."""
     import fused_gtconv as gt
     from DFGNN.layers import preprocess_Hyper_fw_bw
     from DFGNN.operators.fused_gtconv import FusedGTFunction_hyper, GTConvFuse_hyper
     from DFGNN.utils import synthetic as S
     taken = []
     orig = gt.gt_hyper_forward_stats
-    monkeypatch.setattr(gt, "gt_hyper_forward_stats", lambda *a: (taken.append("stats"), orig(*a))[1])
+    monkeypatch.setattr(gt, "gt_hyper_forward_stats", lambda *a, **k: (taken.append("stats"), orig(*a, **k))[1])
 
-    def run(g, weighted=False):
+    def run(g, weighted=False, heads=2):
         A, rows, row_ptr, col_ind, val, col_ptr, row_ind, val_idx, smem = preprocess_Hyper_fw_bw(g)
         if weighted:
             val = (torch.rand_like(val) + 0.5)
         m = g.num_nodes()
-        Q, K, V = (t.requires_grad_(True) for t in S.gt_features(m, 2, 32, seed=9, device=DEV))
-        dO = torch.randn(m, 2, 32, generator=torch.Generator().manual_seed(4)).to(DEV)
+        Q, K, V = (t.requires_grad_(True) for t in S.gt_features(m, heads, 32, seed=9, device=DEV))
+        dO = torch.randn(m, heads, 32, generator=torch.Generator().manual_seed(4)).to(DEV)
         out = GTConvFuse_hyper(rows, row_ptr, col_ind, val, col_ptr, row_ind, val_idx, smem, Q, K, V)
         out.backward(dO)
         n_ = lambda t: t.detach().cpu().numpy()  # noqa: E731
@@ -157,11 +203,21 @@ def test_autograd_function_takes_the_stats_pair_when_it_applies(oracle_mod, monk
     assert taken == ["stats"]
     run(_geometry_batch(1, duplicate=True))          # one range is not dense: the whole batch takes the attn_edge pair
     assert taken == ["stats"]
-    run(_geometry_batch(1), weighted=True)            # edge values: the matrix-core kernels step aside
-    assert taken == ["stats"]
+    run(_geometry_batch(1), weighted=True)            # edge values: the statistics pair reads them in dense form
+    assert taken == ["stats", "stats"]
+    run(_geometry_batch(1), weighted=True, heads=1)   # ... at any head count
+    assert taken == ["stats"] * 3
+    run(_geometry_batch(1, duplicate=True), weighted=True)   # not all dense: the edge-walking kernels
+    assert taken == ["stats"] * 3
+    run(_geometry_batch(1), heads=1)                  # one head: the attn_edge pair is the faster one (the policy's choice)
+    assert taken == ["stats"] * 3
+    monkeypatch.setattr(gt, "STATS_PAIR_MIN_HEADS", 1)  # (DFGNN_STATS=1)
+    run(_geometry_batch(1), heads=1)
+    assert taken == ["stats"] * 4
     monkeypatch.setattr(gt, "USE_STATS_PAIR", False)
     run(_geometry_batch(1))
-    assert taken == ["stats"]
+    run(_geometry_batch(1), weighted=True)
+    assert taken == ["stats"] * 4
     assert FusedGTFunction_hyper is not None
 
 
@@ -276,9 +332,9 @@ def test_stats_kernels_write_nothing_outside_their_outputs(heads):
     L = dfgnn_native.lib()
     P = lambda t: t.data_ptr()  # noqa: E731
     s = torch.cuda.current_stream().cuda_stream
-    assert L.dfgnn_gt_hyper_fwd_stats(m, nnz, heads, f, P(row_ptr), P(col_ind), P(Q), P(K), P(V), P(bufs["mx"][1]),
+    assert L.dfgnn_gt_hyper_fwd_stats(m, nnz, heads, f, P(row_ptr), P(col_ind), None, P(Q), P(K), P(V), P(bufs["mx"][1]),
                                       P(bufs["sm"][1]), P(bufs["out"][1]), plan, meta, s) == 0
-    assert L.dfgnn_gt_bwd_stats(m, nnz, heads, f, P(row_ptr), P(col_ind), P(Q), P(K), P(V), P(bufs["mx"][1]), P(bufs["sm"][1]),
+    assert L.dfgnn_gt_bwd_stats(m, nnz, heads, f, P(row_ptr), P(col_ind), None, P(Q), P(K), P(V), P(bufs["mx"][1]), P(bufs["sm"][1]),
                                 P(dO), P(bufs["dQ"][1]), P(bufs["dK"][1]), P(bufs["dV"][1]), plan, meta, s) == 0
     torch.cuda.synchronize()
     for k, (buf, view) in bufs.items():
@@ -287,9 +343,9 @@ def test_stats_kernels_write_nothing_outside_their_outputs(heads):
     out, mx, sm = gt.gt_hyper_forward_stats(row_ptr, col_ind, Q, K, V)
     assert torch.equal(out.reshape(-1), bufs["out"][1])
     # argument errors: the pair refuses a batch it does not cover instead of computing something else
-    assert L.dfgnn_gt_hyper_fwd_stats(m, nnz, heads, f, P(row_ptr), P(col_ind), P(Q), P(K), P(V), P(bufs["mx"][1]),
+    assert L.dfgnn_gt_hyper_fwd_stats(m, nnz, heads, f, P(row_ptr), P(col_ind), None, P(Q), P(K), P(V), P(bufs["mx"][1]),
                                       P(bufs["sm"][1]), P(bufs["out"][1]), None, None, s) == -2
-    assert L.dfgnn_gt_bwd_stats(m, nnz, heads, f, P(row_ptr), P(col_ind), P(Q), P(K), P(V), None, P(bufs["sm"][1]),
+    assert L.dfgnn_gt_bwd_stats(m, nnz, heads, f, P(row_ptr), P(col_ind), None, P(Q), P(K), P(V), None, P(bufs["sm"][1]),
                                 P(dO), P(bufs["dQ"][1]), P(bufs["dK"][1]), P(bufs["dV"][1]), plan, meta, s) == -1
 
 
@@ -303,7 +359,7 @@ def test_operator_runs_in_a_process_that_opened_the_library_before_torch(tmp_pat
 import ctypes, os, sys
 sys.path[:0] = [%(root)r, os.path.join(%(root)r, 'df-gnn_amd'), os.path.join(%(root)r, 'tests')]
 lib = ctypes.CDLL(os.path.join(%(root)r, 'df-gnn_amd', 'libdfgnn.so'))      # before torch
-assert lib.dfgnn_abi_version() == 9 and 'torch' not in sys.modules
+assert lib.dfgnn_abi_version() == 10 and 'torch' not in sys.modules
 import numpy as np, torch
 import oracle
 from DFGNN.layers import preprocess_Hyper_fw_bw

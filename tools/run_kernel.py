@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Profiling helper: run one hot-path entry point a few times on the C3 workload (for rocprofv3).
-usage: python3 tools/run_kernel.py [fwd|bwd|fwd_stats|bwd_stats|fwd_infer|gat|gat_train|gat_train_drop|c4] [iters] [batch_size]"""
+usage: python3 tools/run_kernel.py [fwd|bwd|fwd_stats|bwd_stats|pairs|fwd_infer|gat|gat_train|gat_train_drop|c4] [iters] [batch_size]"""
 import os
 import sys
 
@@ -51,6 +51,16 @@ if what.startswith("gat_train"):
     for _ in range(iters):
         out, emax, esum, mask = gat.gat_forward(ar, ac, row_ptr, col_ind, 0.2, X, drop)
         gat.gat_backward(0.2, drop, row_ptr, col_ind, col_ptr, row_ind, val_idx, emax, esum, mask, X, ar, ac, dO)
+    torch.cuda.synchronize()
+    print("done", what, iters, m, g.num_edges())
+    sys.exit(0)
+if what == "pairs":  # both GT training pairs, fwd + bwd each (one profiled process covers all four dense kernels)
+    args = (row_ptr, col_ind, rows, val, col_ptr, row_ind, val_idx, smem, Q, K, V)
+    for _ in range(iters):
+        out, attn = gt.gt_hyper_forward(*args)
+        gt.gt_backward(*args, attn, dO)
+        out, rmax, rsum = gt.gt_hyper_forward_stats(row_ptr, col_ind, Q, K, V)
+        gt.gt_backward_stats(row_ptr, col_ind, Q, K, V, rmax, rsum, dO)
     torch.cuda.synchronize()
     print("done", what, iters, m, g.num_edges())
     sys.exit(0)
