@@ -104,7 +104,7 @@ def test_weighted_edges_on_the_matrix_cores(oracle_mod, h, f):
     g = _geometry_batch(29 + f)
     A, rows, row_ptr, col_ind, val, col_ptr, row_ind, val_idx, smem = preprocess_Hyper_fw_bw(g)
     m, nnz = g.num_nodes(), g.num_edges()
-    val = (torch.rand(nnz, 1, generator=torch.Generator().manual_seed(f)) * 2.5 - 1.0).to(DEV)   # in [-1, 1.5)
+    val = (torch.rand(nnz, generator=torch.Generator().manual_seed(f)) * 2.5 - 1.0).to(DEV)   # in [-1, 1.5)
     assert val_ptr(val) is not None
     Q, K, V = S.gt_features(m, h, f, seed=5, device=DEV)
     dO = torch.randn(m, h, f, generator=torch.Generator().manual_seed(3)).to(DEV)

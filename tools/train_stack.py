@@ -88,7 +88,7 @@ def run(args, fuse, dev, overlap=None):
             t_fwd += t2 - t1
             t_bwd += t3 - t2
             edges += g.num_edges() * args.layers
-        loss_v = float(loss)
+        loss_v = float(loss.detach())
     n = args.steps
     return {"mode": ("fused" if fuse else "torch baseline (fuse=False)") +
             ("" if world == 1 else f", {world} ranks, weight-gradient all-reduce " + ("overlapped with the backward" if overlap else "after the backward")),
