@@ -43,8 +43,11 @@ def main():
                     return fused_gtconv.gt_hyper_step_raw(W.row_ptr, W.col_ind, W.rows, W.val, W.col_ptr, W.row_ind,
                                                           W.val_idx, W.smem, W.Q, W.K, W.V, W.dO)[1:]
 
-            eager.append(bench.wall_ms(W.step, reps=args.steps, warm=5))
-            graph.append(bench.wall_ms(GraphedStep(raw_step).replay, reps=args.steps, warm=5))
+            # median of five windows: one host hiccup inside a window (allocator, collector) otherwise shows up as a
+            # 10x outlier of a ~0.1 ms step
+            med = lambda fn: sorted(bench.wall_ms(fn, reps=args.steps, warm=5) for _ in range(5))[2]  # noqa: E731
+            eager.append(med(W.step))
+            graph.append(med(GraphedStep(raw_step).replay))
             sizes.append((len(sub.batch_num_nodes()), W.nnz))
             del W
             torch.cuda.empty_cache()
