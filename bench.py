@@ -8,8 +8,10 @@ the reference.  FusedGTFunction_hyper has two forms of the p
 member graph a dense range of the block plan, unit edge values): the reference's -- the forward writes attn_edge, the
 backward reads it -- and one that saves two floats per (row, head) and recomputes the attention in the backward
 (include/dfgnn.h: dfgnn_gt_hyper_fwd_stats / dfgnn_gt_bwd_stats).  It takes the faster one: the attn_edge pair at one
-head (this headline), the statistics pair from two heads on (--heads 2/4/8).  Both are timed; the one the step does not
-launch is reported under `secondary` (`row_statistics_pair` / `attn_edge_pair`).
+head (this headline) -- with the values in RANK order (by column within a row: dfgnn_gt_hyper_fwd_ranked /
+dfgnn_gt_bwd_ranked; the order is internal to the autograd function, and this one lets the forward find an edge's slot
+from the plan's bitmap instead of the edge list) --, the statistics pair from two heads on (--heads 2/4/8).  All are
+timed; what the step does not launch is reported under `secondary` (`row_statistics_pair` / `attn_edge_pair`).
 Inputs (CSR/COO/CSC index arrays, Q, K, V, dO) are resident in HBM before the timed region.
 
 N > 1: one process per GPU (torch.distributed, RCCL).  Launched by the driver as `python -m torch.distributed.run
@@ -90,6 +92,17 @@ def algorithmic_bytes(m, nnz, h, f):
         # whole backward: reads Q,K,V,dO, attn_edge, CSR + CSC index arrays; writes dQ,dK,dV; the
         # reference's grad_edge round trip (8 h nnz) is part of the figure even though the resident kernel avoids it
         "gt_bwd": 28 * m * D + 12 * h * nnz + 16 * nnz + 8 * (m + 1),
+    }
+
+
+def algorithmic_bytes_ranked(m, nnz, h, f):
+    """The attn_edge pair with the values in rank order (dfgnn_gt_hyper_fwd_ranked / dfgnn_gt_bwd_ranked).  Forward: what it
+    moves -- Q, K, V in, out and attn_edge out, row_ptr and the out-edge bitmap in (no rows / col_ind / val: 12 nnz less than
+    SURVEY.md 8(d) counts).  Backward: the kernel and the figure of the attn_edge pair."""
+    D = h * f
+    return {
+        "gt_hyper_fwd_ranked": 16 * m * D + 4 * h * nnz + 4 * (m + 1) + 32 * m,
+        "gt_bwd_ranked": algorithmic_bytes(m, nnz, h, f)["gt_bwd"],
     }
 
 
@@ -358,11 +371,23 @@ def main():
     reps = max(10, args.steps)
     attn_us = {"gt_hyper_fwd": ev_us(checked(fwd_call(VP)), reps), "gt_bwd": ev_us(checked(bwd_call(VP)), reps)}
     attn_bytes = algorithmic_bytes(m, nnz, h, f)
+    # one head, all dense, unit values: the attn_edge pair in rank order is what the step launches
+    ranked_can = fused_gtconv.gt_ranked_pair_applies(W.row_ptr, W.col_ind, W.val, W.Q) if uses_stats is None else None
+    ranked_us = None
+    if ranked_can is not None:
+        ranked_us = {
+            "gt_hyper_fwd_ranked": ev_us(checked(lambda: L.dfgnn_gt_hyper_fwd_ranked(
+                m, nnz, h, f, P(W.row_ptr), P(W.col_ind), P(W.Q), P(W.K), P(W.V), P(attn), P(out), plan, plan_meta, stream)), reps),
+            "gt_bwd_ranked": ev_us(checked(lambda: L.dfgnn_gt_bwd_ranked(
+                m, nnz, h, f, P(W.row_ptr), P(W.col_ind), P(W.Q), P(W.K), P(W.V), P(attn), P(W.dO), P(dQ), P(dK), P(dV), plan,
+                plan_meta, stream)), reps)}
     stats_us, stats_bytes = None, algorithmic_bytes_stats(m, nnz, h, f)
     if stats_can is not None:
         stats_us = {"gt_hyper_fwd_stats": ev_us(checked(fwd_stats_call), reps), "gt_bwd_stats": ev_us(checked(bwd_stats_call), reps)}
     if uses_stats is not None:
         kernel_us, abytes = stats_us, stats_bytes
+    elif ranked_us is not None:
+        kernel_us, abytes = ranked_us, algorithmic_bytes_ranked(m, nnz, h, f)
     else:
         kernel_us, abytes = attn_us, attn_bytes
     # edge values other than ones: the statistics pair with the values in the plan's dense form (what FusedGTFunction_hyper
@@ -401,6 +426,7 @@ def main():
         if (prof.get("m") == m and prof.get("nnz") == nnz and prof.get("h") == h and prof.get("f") == f and
                 prof.get("build_id") == dfgnn_native.build_id()):
             key = {"gt_hyper_fwd": "gt_dense_fwd_kernel", "gt_bwd": "gt_dense_bwd_kernel",
+                   "gt_hyper_fwd_ranked": "gt_dense_fwd_ranked_kernel", "gt_bwd_ranked": "gt_dense_bwd_kernel",
                    "gt_hyper_fwd_stats": "gt_dense_fwd_stats_kernel", "gt_bwd_stats": "gt_dense_bwd_stats_kernel"}[dom]
             traffic = int(prof["traffic"][key]["total_bytes"])
             traffic_src = PMC_PROFILE + (" (library build %s)" % prof.get("build_id", "?"))
@@ -464,18 +490,13 @@ def main():
 
         def raw_step():  # the launches of the timed step as explicit operator calls (no autograd bookkeeping)
             with torch.no_grad():
-                if uses_stats is not None:
-                    o, mx_, sm_ = fused_gtconv.gt_hyper_forward_stats(W.row_ptr, W.col_ind, W.Q, W.K, W.V)
-                    return fused_gtconv.gt_backward_stats(W.row_ptr, W.col_ind, W.Q, W.K, W.V, mx_, sm_, W.dO)
-                o, at = fused_gtconv.gt_hyper_forward(W.row_ptr, W.col_ind, W.rows, W.val, W.col_ptr, W.row_ind, W.val_idx,
-                                                      W.smem, W.Q, W.K, W.V)
-                return fused_gtconv.gt_backward(W.row_ptr, W.col_ind, W.rows, W.val, W.col_ptr, W.row_ind, W.val_idx, W.smem,
-                                                W.Q, W.K, W.V, at, W.dO)
+                return fused_gtconv.gt_hyper_step_raw(W.row_ptr, W.col_ind, W.rows, W.val, W.col_ptr, W.row_ind, W.val_idx,
+                                                      W.smem, W.Q, W.K, W.V, W.dO)[1:]
 
         graphed = GraphedStep(raw_step)
         secondary = {
-            # the reference's form of the pair (attn_edge written by the forward, read by the backward), same batch, same
-            # launches as round 2's headline; SURVEY.md 8(d) bytes
+            # the reference's form of the pair (attn_edge in CSR order written by the forward, read by the backward), same
+            # batch, same launches as round 2's headline; SURVEY.md 8(d) bytes
             "attn_edge_pair": {k: {"avg_us": round(v, 2), "algorithmic_bytes": attn_bytes[k],
                                    "frac": round(attn_bytes[k] / (v * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)} for k, v in attn_us.items()},
             # the pair that saves row statistics instead of attn_edge (what the step launches from two heads on)
@@ -546,6 +567,7 @@ def main():
             "config": {"workload": f"GT conv 'hyper' fwd+bwd, PATTERN-like batch bs={args.batch_size} "
                                    f"dim={args.dim} heads={h} (BASELINE.json configs[2])",
                        "training_pair": "row statistics (dfgnn_gt_hyper_fwd_stats / dfgnn_gt_bwd_stats)" if uses_stats is not None
+                       else "attn_edge in rank order (dfgnn_gt_hyper_fwd_ranked / dfgnn_gt_bwd_ranked)" if ranked_us is not None
                        else "attn_edge (dfgnn_gt_hyper_fwd / dfgnn_gt_bwd)",
                        "nodes_per_gpu": m, "edges_per_gpu": nnz, "total_edges": total_edges,
                        "parallelism": (f"graph-sharded x{world} ({args.scaling} scaling), no data-path collective")},

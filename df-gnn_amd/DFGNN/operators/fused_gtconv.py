@@ -28,7 +28,9 @@ class FusedGTFunction_hyper(torch.autograd.Function):
     heads or edge values other than ones (fused_gt.gt_stats_pair_chosen: there it is the faster pair, measured) the
     forward saves two floats per (row, head) instead -- logit maximum and sum of exponentials -- and the backward
     recomputes the attention (include/dfgnn.h: dfgnn_gt_hyper_fwd_stats / dfgnn_gt_bwd_stats): same gradients, 8 h nnz
-    bytes less through HBM.  Any other batch takes the reference's form below it."""
+    bytes less through HBM.  At one head with unit values such a batch keeps the reference's form but with attn_edge in
+    RANK order (by column within a row: fused_gt.gt_ranked_pair_applies), which spares the forward the edge list and the
+    position map.  Any other batch takes the reference's form below them."""
 
     @staticmethod
     def forward(ctx, rows, row_ptr, col_ind, val, col_ptr, row_ind, val_idx, smem_consume, Q, K, V):
@@ -37,6 +39,11 @@ class FusedGTFunction_hyper(torch.autograd.Function):
         if ctx.stats is not None:
             out_feat, row_max, row_sum = fused_gt.gt_hyper_forward_stats(row_ptr, col_ind, Q, K, V, ctx.stats, val)
             ctx.save_for_backward(row_ptr, col_ind, Q, K, V, row_max, row_sum, val)
+            return out_feat
+        ctx.ranked = fused_gt.gt_ranked_pair_applies(row_ptr, col_ind, val, Q)   # the block plan, or None
+        if ctx.ranked is not None:   # one head, all dense, unit values: attn_edge in rank order (same pair, cheaper forward)
+            out_feat, attn_ranked = fused_gt.gt_hyper_forward_ranked(row_ptr, col_ind, Q, K, V, ctx.ranked)
+            ctx.save_for_backward(row_ptr, col_ind, Q, K, V, attn_ranked)
             return out_feat
         out_feat, attn_edge = fused_gt.gt_hyper_forward(
             row_ptr, col_ind, rows, val, col_ptr, row_ind, val_idx, smem_consume, Q, K, V)
@@ -49,6 +56,11 @@ class FusedGTFunction_hyper(torch.autograd.Function):
             row_ptr, col_ind, Q, K, V, row_max, row_sum, val = ctx.saved_tensors
             grad_Q, grad_K, grad_V = fused_gt.gt_backward_stats(row_ptr, col_ind, Q, K, V, row_max, row_sum,
                                                                 grad_out.contiguous(), ctx.stats, val)
+            return (None,) * 8 + (grad_Q, grad_K, grad_V)
+        if ctx.ranked is not None:
+            row_ptr, col_ind, Q, K, V, attn_ranked = ctx.saved_tensors
+            grad_Q, grad_K, grad_V = fused_gt.gt_backward_ranked(row_ptr, col_ind, Q, K, V, attn_ranked,
+                                                                 grad_out.contiguous(), ctx.ranked)
             return (None,) * 8 + (grad_Q, grad_K, grad_V)
         row_ptr, col_ind, rows, val, col_ptr, row_ind, val_idx, Q, K, V, attn_edge = ctx.saved_tensors
         grad_Q, grad_K, grad_V = fused_gt.gt_backward(

@@ -36,7 +36,10 @@ __device__ __forceinline__ void dense_fwd_body(float *lds, int lds_bytes, const 
                                                float *__restrict__ stat_max = nullptr,
                                                float *__restrict__ stat_sum = nullptr,
                                                const DenseDrop drop = DenseDrop{}) {
-  static_assert(!(STATS && (WRITE_ATTN || GAT)), "the statistics-saving forward writes no attention values");
+  static_assert(!(STATS && GAT), "the bitmap-driven forward is a GT form");
+  // STATS && WRITE_ATTN: the "ranked" training forward -- edges from the bitmaps, attention values written in RANK order
+  // (row i's k-th edge by increasing column at row_ptr[i] + k; the slot of a pair = the number of set bits before it),
+  // which the backward reads back with the plan's rank-ordered coordinates: no byte map, no edge loads, no scatter
   constexpr int F = FR < 32 ? 32 : FR;  // layout width
   constexpr int fr = FR;
   static_assert(!WEIGHTED || (STATS && !GAT), "dense edge values go with the bitmap-masked (STATS) GT forward");
@@ -74,7 +77,7 @@ __device__ __forceinline__ void dense_fwd_body(float *lds, int lds_bytes, const 
   //      first go first (memory returns in order: behind the big loads they would wait for all of them) ---------------
   int rp_mine = 0;       // row_ptr[n0 + tid] (n <= 255: one entry per thread covers the range)
   float ac_mine = 0.f;   // GAT: attn_col[n0 + tid]
-  if constexpr (!STATS) {
+  if constexpr (!STATS || WRITE_ATTN) {
     const int tid = opaque_tid();
     if (tid <= n) rp_mine = g.row_ptr[n0 + tid];
     if constexpr (GAT)
@@ -131,6 +134,10 @@ __device__ __forceinline__ void dense_fwd_body(float *lds, int lds_bytes, const 
 #pragma unroll
       for (int w = 0; w < MW; ++w) mwords[s][w] = ld32(mp, (unsigned)w);
     }
+  }
+  if constexpr (STATS && WRITE_ATTN) {  // (read long after the image barriers below)
+    const int tid = opaque_tid();
+    if (tid <= n) rp[tid] = rp_mine - e0;
   }
   if constexpr (!STATS) {
     const int tid = opaque_tid();
@@ -322,6 +329,22 @@ __device__ __forceinline__ void dense_fwd_body(float *lds, int lds_bytes, const 
         if (i < n) {
           float *lrow = pstage + rp[i];
           float *grow = attn_edge + (size_t)hd * g.nnz + e0 + rp[i];
+          // the 4 slots of tile jt as one word, 0xFF = no edge: from the byte map, or (STATS) the ranks of the pairs among
+          // the set bits of the row's bitmap -- bits before this lane's 4 within the word + the words before it
+          unsigned before = 0;  // (STATS) set bits of the words in front of the current one
+          auto slots_of = [&](int jt) -> unsigned {
+            if constexpr (!STATS) {
+              return *reinterpret_cast<const unsigned *>(mrow + 16 * jt);
+            } else {
+              const unsigned word = mwords[s][jt / 2], low = 16u * (jt & 1) + 4u * L.mq;
+              const unsigned b4 = (word >> low) & 0xFu;
+              const unsigned r0 = before + __popc(word & ((1u << low) - 1u));
+              const unsigned r1 = r0 + (b4 & 1u), r2 = r1 + ((b4 >> 1) & 1u), r3 = r2 + ((b4 >> 2) & 1u);
+              if (jt & 1) before += __popc(word);
+              return ((b4 & 1u) ? r0 : 0xFFu) | (((b4 & 2u) ? r1 : 0xFFu) << 8) | (((b4 & 4u) ? r2 : 0xFFu) << 16) |
+                     (((b4 & 8u) ? r3 : 0xFFu) << 24);
+            }
+          };
           if (stage_attn) {
             // LDS staging, branch-free: a pair that is no edge writes into this lane's own dump word instead of being
             // masked out (an exec-mask round trip per pair costs more than the store)
@@ -329,7 +352,7 @@ __device__ __forceinline__ void dense_fwd_body(float *lds, int lds_bytes, const 
 #pragma unroll
             for (int jt = 0; jt < NT; ++jt) {
               if (jt < ntile) {
-                const unsigned w = *reinterpret_cast<const unsigned *>(mrow + 16 * jt);
+                const unsigned w = slots_of(jt);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                   const unsigned slot = (w >> (8 * r)) & 0xFFu;
@@ -342,7 +365,7 @@ __device__ __forceinline__ void dense_fwd_body(float *lds, int lds_bytes, const 
 #pragma unroll
             for (int jt = 0; jt < NT; ++jt) {
               if (jt < ntile) {
-                const unsigned w = *reinterpret_cast<const unsigned *>(mrow + 16 * jt);
+                const unsigned w = slots_of(jt);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                   const unsigned slot = (w >> (8 * r)) & 0xFFu;

@@ -68,6 +68,11 @@ struct Plan {              // host view of a built plan (see plan.hip for the de
   size_t mask_off() const { return plan_mask_off((size_t)coords_off, nnz); }
   const unsigned *mask() const { return reinterpret_cast<const unsigned *>(dev + mask_off()); }
   const unsigned *maskT() const { return mask() + 8 * (size_t)m; }
+  // ... and behind the bitmaps the coordinates once more, in RANK order: position row_ptr[i] + k holds (row, column) of the
+  // k-th edge of row i by increasing column -- the order the bitmap-driven forward writes attention values in
+  // (gt_dense_fwd_ranked_kernel) and its backward therefore reads them in
+  size_t ranked_off() const { return mask_off() + 2 * (size_t)kPlanMaskWords * (size_t)m; }
+  const unsigned short *coords_ranked() const { return reinterpret_cast<const unsigned short *>(dev + ranked_off()); }
   const int *fit() const { return dev + kPlanHeader; }
   const int *spill() const { return dev + kPlanHeader + 2 * (size_t)m; }
 };
@@ -119,7 +124,7 @@ int launch_gt_dense_fwd(const Csr &g, const Plan &p, const float *Q, const float
                         float *attn_edge, float *out, hipStream_t s);
 int launch_gt_dense_bwd(const Csr &g, const Plan &p, const float *Q, const float *K, const float *V,
                         const float *attn_edge, const float *grad_out, float *dQ, float *dK, float *dV,
-                        hipStream_t s);
+                        hipStream_t s, bool ranked = false);
 // the statistics-saving training pair (gt_dense_stats.hip): no attn_edge, row statistics [m, h] instead
 int launch_gt_dense_fwd_stats(const Csr &g, const Plan &p, const float *Q, const float *K, const float *V, float *out,
                               float *stat_max, float *stat_sum, hipStream_t s);
@@ -133,6 +138,10 @@ int launch_gt_dense_fwd_stats_w(const Csr &g, const Plan &p, const float *Q, con
 int launch_gt_dense_bwd_stats_w(const Csr &g, const Plan &p, const float *Q, const float *K, const float *V,
                                 const float *stat_max, const float *stat_sum, const float *grad_out, float *dQ, float *dK,
                                 float *dV, hipStream_t s);
+// the attn_edge pair with the values in RANK order (gt_dense_stats_w.hip; one head): the forward is bitmap-driven, the
+// backward is launch_gt_dense_bwd with ranked = true (the plan's rank-ordered coordinates)
+int launch_gt_dense_fwd_ranked(const Csr &g, const Plan &p, const float *Q, const float *K, const float *V,
+                               float *attn_ranked, float *out, hipStream_t s);
 // edge_max / edge_sum (nullable): row statistics for the GAT training pair
 int launch_gat_dense_fwd(const Csr &g, const Plan &p, const float *attn_row, const float *attn_col, float slope,
                          const float *X, float *out, hipStream_t s, float *edge_max = nullptr,

@@ -316,9 +316,9 @@ int launch_gat_dense_bwd(const Csr &g_in, const Plan &p, const float *attn_row, 
 
 int launch_gt_dense_bwd(const Csr &g_in, const Plan &p, const float *Q, const float *K, const float *V,
                         const float *attn_edge, const float *grad_out, float *dQ, float *dK, float *dV,
-                        hipStream_t s) {
+                        hipStream_t s, bool ranked) {
   Csr g = g_in;
-  g.coords = p.coords();
+  g.coords = ranked ? p.coords_ranked() : p.coords();  // ranked: attn_edge is in rank order (launch_gt_dense_fwd_ranked)
   if (p.num_dense == 0) return 0;
   // multi-head, heads of at most 64 features: one workgroup per range of <= 128 nodes walks the heads (see the kernel)
   const int walk = (g.h > 1 && g.f <= 64) ? min(heads_walk(), g.h) : 0;

@@ -69,6 +69,32 @@ __global__ __launch_bounds__(kDenseThreads) void gt_dense_bwd_stats_w_kernel(
     dense_bwd_body<F, kDenseChunkRows, 2, false, true, true>(lds, g, n0, n, 0, 0, head, Q, K, V, nullptr, dO, dQ, dK, dV, st);
 }
 
+// ---- the "ranked" training forward (one head): attn_edge written, but in RANK order -------------------------------------
+// The attn_edge pair's forward spends a fifth of its time on the sparse structure: 2 B of coordinates per edge, a byte map
+// (cleared, scattered into, read back) to find an edge's CSR position.  What the autograd pair needs is only that forward
+// and backward agree on an order -- so this forward takes the edges from the bitmaps like the statistics forward and
+// writes the value of row i's k-th edge BY INCREASING COLUMN to row_ptr[i] + k (the slot of a pair = the set bits before
+// it), and gt_dense_bwd_kernel reads the values back with the plan's rank-ordered coordinates instead of the CSR-ordered
+// ones: the backward is the same kernel at the same cost.  gt_hyper_forward -> [out, attn_edge] for direct callers keeps
+// the CSR order (gt_dense_fwd_kernel).
+template <int F>
+__global__ __launch_bounds__(kDenseThreads) void gt_dense_fwd_ranked_kernel(Csr g, const int *__restrict__ fit,
+                                                                            const float *__restrict__ Q,
+                                                                            const float *__restrict__ K,
+                                                                            const float *__restrict__ V,
+                                                                            float *__restrict__ attn_ranked,
+                                                                            float *__restrict__ out, int lds_bytes) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int n0 = fit[2 * blockIdx.x], n1 = fit[2 * blockIdx.x + 1] & kPlanRangeMask;
+  const int n = n1 - n0, e0 = g.row_ptr[n0], ne = g.row_ptr[n1] - e0;
+  if (n <= kDenseChunkRows)
+    dense_fwd_body<F, true, 1, kDenseChunkRows, 1, false, false, true>(lds, lds_bytes, g, n0, n, e0, ne, 0, 1, Q, K, V, attn_ranked, out);
+  else if (n <= kDenseWideRows)
+    dense_fwd_body<F, true, 2, kDenseWideRows, 1, false, false, true>(lds, lds_bytes, g, n0, n, e0, ne, 0, 1, Q, K, V, attn_ranked, out);
+  else
+    dense_fwd_body<F, true, 2, kDenseChunkRows, 2, false, false, true>(lds, lds_bytes, g, n0, n, e0, ne, 0, 1, Q, K, V, attn_ranked, out);
+}
+
 template <class Fn>
 static int dispatch_dense_w(int f, Fn &&fn) {
   if (f == 8) return fn(std::integral_constant<int, 8>{});  // f = 8 / 16: zero-padded onto the 32-wide layout
@@ -100,6 +126,20 @@ int launch_gt_dense_bwd_stats_w(const Csr &g, const Plan &p, const float *Q, con
     if (int rc = set_max_lds_cached(gt_dense_bwd_stats_w_kernel<F>)) return rc;
     gt_dense_bwd_stats_w_kernel<F><<<grid, kDenseThreads, kLdsBytes, s>>>(g, p.fit(), Q, K, V, stat_max, stat_sum, grad_out, dQ,
                                                                           dK, dV);
+    return launch_status();
+  });
+}
+
+int launch_gt_dense_fwd_ranked(const Csr &g_in, const Plan &p, const float *Q, const float *K, const float *V,
+                               float *attn_ranked, float *out, hipStream_t s) {
+  if (p.num_dense == 0) return 0;
+  Csr g = g_in;
+  g.mask = p.mask();
+  const dim3 grid(p.num_dense, 1);
+  return dispatch_dense_w(g.f, [&](auto fc) {
+    constexpr int F = decltype(fc)::value;
+    if (int rc = set_max_lds_cached(gt_dense_fwd_ranked_kernel<F>)) return rc;
+    gt_dense_fwd_ranked_kernel<F><<<grid, kDenseThreads, kLdsBytes, s>>>(g, p.fit(), Q, K, V, attn_ranked, out, kLdsBytes);
     return launch_status();
   });
 }

@@ -385,7 +385,8 @@ __global__ __launch_bounds__(kPlanThreads) void plan_cut_kernel(int m, int nnz, 
 __global__ __launch_bounds__(256) void plan_coords_kernel(const int *__restrict__ row_ptr,
                                                           const int *__restrict__ col_ind, const int *plan,
                                                           unsigned short *__restrict__ coords,
-                                                          unsigned *__restrict__ mask, unsigned *__restrict__ maskT) {
+                                                          unsigned *__restrict__ mask, unsigned *__restrict__ maskT,
+                                                          unsigned short *__restrict__ ranked) {
   __shared__ unsigned s_mask[2][256 * kPlanMaskWords];
   const int ndense = plan[9];
   const int *fit = plan + kPlanHeader;
@@ -408,6 +409,12 @@ __global__ __launch_bounds__(256) void plan_coords_kernel(const int *__restrict_
     for (int t = threadIdx.x; t < words; t += 256) {
       mask[(size_t)n0 * kPlanMaskWords + t] = s_mask[0][t];
       maskT[(size_t)n0 * kPlanMaskWords + t] = s_mask[1][t];
+      // the coordinates in rank order: word t of row r lists its set bits behind those of the row's earlier words
+      const int r = t / kPlanMaskWords, w = t % kPlanMaskWords;
+      int at = row_ptr[n0 + r];
+      for (int v = 0; v < w; ++v) at += __popc(s_mask[0][r * kPlanMaskWords + v]);
+      for (unsigned bits = s_mask[0][t]; bits; bits &= bits - 1)
+        ranked[at++] = (unsigned short)((r << 8) | (32 * w + (__ffs(bits) - 1)));
     }
     __syncthreads();
   }
@@ -454,7 +461,7 @@ static size_t plan_coords_off(int m) {
 }
 size_t dfgnn_plan_ints(int m, int nnz) {
   if (m < 0 || nnz < 0) return 0;
-  return plan_mask_off(plan_coords_off(m), nnz) + 2 * (size_t)kPlanMaskWords * (size_t)m + 4;
+  return plan_mask_off(plan_coords_off(m), nnz) + 2 * (size_t)kPlanMaskWords * (size_t)m + ((size_t)nnz + 1) / 2 + 4;
 }
 
 int dfgnn_plan_build(int m, int nnz, int f, const int *row_ptr, const int *col_ind, int *plan, int *meta_host,
@@ -497,7 +504,8 @@ int dfgnn_plan_build(int m, int nnz, int f, const int *row_ptr, const int *col_i
     unsigned *mask = reinterpret_cast<unsigned *>(plan + plan_mask_off(coords_off, nnz));
     plan_coords_kernel<<<(unsigned)min(m, 2048), 256, 0, s>>>(row_ptr, col_ind, plan,
                                                              reinterpret_cast<unsigned short *>(plan + coords_off), mask,
-                                                             mask + (size_t)kPlanMaskWords * m);
+                                                             mask + (size_t)kPlanMaskWords * m,
+                                                             reinterpret_cast<unsigned short *>(mask + 2 * (size_t)kPlanMaskWords * m));
     if (int rc = launch_status()) return rc;
   }
   if (hipError_t rc = hipMemcpyAsync(meta_host, plan, kPlanHeader * sizeof(int), hipMemcpyDeviceToHost, s)) return (int)rc;

@@ -205,6 +205,37 @@ std::vector<Tensor> gt_bwd_stats(const Tensor &row_ptr, const Tensor &col_ind, c
   return {dQ, dK, dV};
 }
 
+// ---- the attn_edge pair in rank order (include/dfgnn.h: dfgnn_gt_hyper_fwd_ranked / dfgnn_gt_bwd_ranked) ----------------
+std::vector<Tensor> gt_hyper_fwd_ranked(const Tensor &row_ptr, const Tensor &col_ind, const Tensor &Q, const Tensor &K,
+                                        const Tensor &V, int64_t plan, int64_t meta) {
+  const GtDims d = gt_stats_checks(row_ptr, col_ind, Q, K, V);
+  c10::hip::HIPGuardMasqueradingAsCUDA guard(Q.device());
+  Tensor out = torch::empty_like(Q);
+  Tensor attn = torch::empty({d.h, d.nnz}, Q.options());
+  check_rc(dfgnn_gt_hyper_fwd_ranked(d.m, d.nnz, d.h, d.f, row_ptr.data_ptr<int>(), col_ind.data_ptr<int>(), Q.data_ptr<float>(),
+                                     K.data_ptr<float>(), V.data_ptr<float>(), attn.data_ptr<float>(), out.data_ptr<float>(),
+                                     plan_ptr(plan), plan_ptr(meta), cur_stream()),
+           "gt_hyper_forward_ranked");
+  return {out, attn};
+}
+
+std::vector<Tensor> gt_bwd_ranked(const Tensor &row_ptr, const Tensor &col_ind, const Tensor &Q, const Tensor &K,
+                                  const Tensor &V, const Tensor &attn, const Tensor &grad, int64_t plan, int64_t meta) {
+  const GtDims d = gt_stats_checks(row_ptr, col_ind, Q, K, V);
+  check_feat3(grad, Q, "grad");
+  check_f32(attn, "attn_ranked");
+  TORCH_CHECK(attn.numel() == (int64_t)d.h * d.nnz, "attn_ranked must have ", d.h, "*", d.nnz, " elements, got ", attn.numel());
+  TORCH_CHECK(attn.device() == Q.device() && grad.device() == Q.device(), "attn_ranked / grad must live on the device of Q");
+  c10::hip::HIPGuardMasqueradingAsCUDA guard(Q.device());
+  Tensor dQ = torch::empty_like(Q), dK = torch::empty_like(K), dV = torch::empty_like(V);
+  check_rc(dfgnn_gt_bwd_ranked(d.m, d.nnz, d.h, d.f, row_ptr.data_ptr<int>(), col_ind.data_ptr<int>(), Q.data_ptr<float>(),
+                               K.data_ptr<float>(), V.data_ptr<float>(), attn.data_ptr<float>(), grad.data_ptr<float>(),
+                               dQ.data_ptr<float>(), dK.data_ptr<float>(), dV.data_ptr<float>(), plan_ptr(plan), plan_ptr(meta),
+                               cur_stream()),
+           "gt_backward_ranked");
+  return {dQ, dK, dV};
+}
+
 // the edge values of a plan's dense ranges in dense form (dfgnn_plan_dense_weights): fp32[256 m]
 Tensor plan_dense_weights(const Tensor &row_ptr, const Tensor &val, int64_t plan, int64_t meta) {
   check_i32(row_ptr, "row_ptr");
@@ -459,6 +490,8 @@ PYBIND11_MODULE(_dfgnn_ext, m) {
   m.def("gt_bwd", &gt_bwd, "fused GT conv backward");
   m.def("gt_hyper_fwd_stats", &gt_hyper_fwd_stats, "fused GT conv 'hyper' training forward, row statistics instead of attn_edge");
   m.def("gt_bwd_stats", &gt_bwd_stats, "fused GT conv backward from the row statistics");
+  m.def("gt_hyper_fwd_ranked", &gt_hyper_fwd_ranked, "fused GT conv 'hyper' training forward, attention values in rank order");
+  m.def("gt_bwd_ranked", &gt_bwd_ranked, "fused GT conv backward from rank-ordered attention values");
   m.def("plan_dense_weights", &plan_dense_weights, "edge values of a plan's dense ranges in dense form (dfgnn_plan_dense_weights)");
   m.def("gat_hyper_fwd", &gat_hyper_fwd, "fused GAT conv 'hyper' inference");
   m.def("gat_softmax_fwd", &gat_softmax_fwd, "fused GAT conv 'softmax' / 'softmax_gm' inference");

@@ -26,6 +26,8 @@ SIGNATURES = {
     "dfgnn_gt_hyper_fwd_stats": [_i, _i, _i, _i] + [_vp] * 12,
     "dfgnn_gt_bwd_stats": [_i, _i, _i, _i] + [_vp] * 15,
     "dfgnn_plan_dense_weights": [_i, _i] + [_vp] * 6,
+    "dfgnn_gt_hyper_fwd_ranked": [_i, _i, _i, _i] + [_vp] * 10,
+    "dfgnn_gt_bwd_ranked": [_i, _i, _i, _i] + [_vp] * 13,
     "dfgnn_gt_bwd_rows": [_i, _i, _i, _i] + [_vp] * 11,
     "dfgnn_gt_bwd_cols": [_i, _i, _i, _i] + [_vp] * 11,
     "dfgnn_gt_tiling_fwd": [_i, _i, _i, _i] + [_vp] * 8,

@@ -184,6 +184,71 @@ def _stats_weights(plan, row_ptr, val):
     return plan_dense_weights(plan, row_ptr, val)
 
 
+# ---- the attn_edge pair in rank order (include/dfgnn.h: dfgnn_gt_hyper_fwd_ranked / dfgnn_gt_bwd_ranked) --------------
+# What FusedGTFunction_hyper takes at ONE head on an all-dense batch with unit edge values: the attention values travel from
+# forward to backward like in the reference, but ordered by column within a row, which lets the forward find an edge's slot
+# from the plan's bitmap instead of the edge list (csrc/gt_dense_stats_w.hip: gt_dense_fwd_ranked_kernel).
+USE_RANKED_PAIR = os.environ.get("DFGNN_RANKED", "1") != "0"
+
+
+def gt_ranked_pair_applies(row_ptr, col_ind, val, Q):
+    """The block plan when gt_hyper_forward_ranked / gt_backward_ranked can serve this call, else None."""
+    if not (USE_RANKED_PAIR and USE_BLOCK_PLAN) or Q.dim() != 3 or not Q.is_cuda or Q.size(1) != 1 or val_ptr(val) is not None:
+        return None
+    plan = get_plan_obj(row_ptr, col_ind, Q.size(-1), True)
+    if plan is not None and plan.stats_applies(1):
+        return plan
+    return None
+
+
+def gt_hyper_forward_ranked(row_ptr, col_ind, Q, K, V, plan=None):
+    """-> [out, attn_ranked[1, nnz]] (row i's k-th edge by increasing column at row_ptr[i] + k)."""
+    if plan is None:
+        plan = get_plan_obj(row_ptr, col_ind, Q.size(-1) if Q.dim() == 3 else 0, USE_BLOCK_PLAN)
+    pp, mp = plan.ptrs() if plan is not None else (None, None)
+    ext = _n.ext()
+    if ext is not None and hasattr(ext, "gt_hyper_fwd_ranked"):
+        return ext.gt_hyper_fwd_ranked(row_ptr, col_ind, Q, K, V, pp or 0, mp or 0)
+    check_device(row_ptr=row_ptr, col_ind=col_ind)
+    check_contiguous(row_ptr=row_ptr, col_ind=col_ind)
+    check_dtype(torch.int32, row_ptr=row_ptr, col_ind=col_ind)
+    _check_qkv(Q, K, V)
+    m, nnz, h, f = _dims(row_ptr, col_ind, Q)
+    _check_graph(row_ptr, col_ind, Q.size(0))
+    with torch.cuda.device(Q.device):
+        out = torch.empty_like(Q)
+        attn = torch.empty((h, nnz), dtype=torch.float32, device=Q.device)
+        _n.check(_n.lib().dfgnn_gt_hyper_fwd_ranked(m, nnz, h, f, ptr(row_ptr), ptr(col_ind), ptr(Q), ptr(K), ptr(V), ptr(attn),
+                                                    ptr(out), pp, mp, stream_ptr(Q.device)), "gt_hyper_forward_ranked")
+    return [out, attn]
+
+
+def gt_backward_ranked(row_ptr, col_ind, Q, K, V, attn_ranked, grad, plan=None):
+    """-> [dQ, dK, dV] from the rank-ordered attention values of gt_hyper_forward_ranked."""
+    if plan is None:
+        plan = get_plan_obj(row_ptr, col_ind, Q.size(-1) if Q.dim() == 3 else 0, USE_BLOCK_PLAN)
+    pp, mp = plan.ptrs() if plan is not None else (None, None)
+    ext = _n.ext()
+    if ext is not None and hasattr(ext, "gt_bwd_ranked"):
+        return ext.gt_bwd_ranked(row_ptr, col_ind, Q, K, V, attn_ranked, grad, pp or 0, mp or 0)
+    check_device(row_ptr=row_ptr, col_ind=col_ind, attn_ranked=attn_ranked, grad=grad)
+    check_contiguous(row_ptr=row_ptr, col_ind=col_ind, attn_ranked=attn_ranked, grad=grad)
+    check_dtype(torch.int32, row_ptr=row_ptr, col_ind=col_ind)
+    check_dtype(torch.float32, attn_ranked=attn_ranked, grad=grad)
+    _check_qkv(Q, K, V)
+    check_feat3(Q=Q, grad=grad)
+    m, nnz, h, f = _dims(row_ptr, col_ind, Q)
+    _check_graph(row_ptr, col_ind, Q.size(0))
+    if attn_ranked.numel() != h * nnz:
+        raise RuntimeError(f"attn_ranked must have {h}*{nnz} elements, got {attn_ranked.numel()}")
+    with torch.cuda.device(Q.device):
+        dQ, dK, dV = torch.empty_like(Q), torch.empty_like(K), torch.empty_like(V)
+        _n.check(_n.lib().dfgnn_gt_bwd_ranked(m, nnz, h, f, ptr(row_ptr), ptr(col_ind), ptr(Q), ptr(K), ptr(V), ptr(attn_ranked),
+                                              ptr(grad), ptr(dQ), ptr(dK), ptr(dV), pp, mp, stream_ptr(Q.device)),
+                 "gt_backward_ranked")
+    return [dQ, dK, dV]
+
+
 def gt_hyper_step_raw(row_ptr, col_ind, rows, val, col_ptr, row_ind, val_idx, smem, Q, K, V, grad):
     """-> [out, dQ, dK, dV]: the launches of one FusedGTFunction_hyper forward + backward as explicit operator calls (no
     autograd graph), choosing the pair the way the autograd function does -- what the HIP-graph replays capture."""
@@ -191,6 +256,10 @@ def gt_hyper_step_raw(row_ptr, col_ind, rows, val, col_ptr, row_ind, val_idx, sm
     if plan is not None:
         out, rmax, rsum = gt_hyper_forward_stats(row_ptr, col_ind, Q, K, V, plan=plan, val=val)
         return [out] + list(gt_backward_stats(row_ptr, col_ind, Q, K, V, rmax, rsum, grad, plan=plan, val=val))
+    plan = gt_ranked_pair_applies(row_ptr, col_ind, val, Q)
+    if plan is not None:
+        out, attn = gt_hyper_forward_ranked(row_ptr, col_ind, Q, K, V, plan=plan)
+        return [out] + list(gt_backward_ranked(row_ptr, col_ind, Q, K, V, attn, grad, plan=plan))
     out, attn = gt_hyper_forward(row_ptr, col_ind, rows, val, col_ptr, row_ind, val_idx, smem, Q, K, V)
     return [out] + list(gt_backward(row_ptr, col_ind, rows, val, col_ptr, row_ind, val_idx, smem, Q, K, V, attn, grad))
 

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define DFGNN_ABI_VERSION 10
+#define DFGNN_ABI_VERSION 11
 
 #define DFGNN_E_BADARG (-1)      /* negative size / NULL required pointer                      */
 #define DFGNN_E_UNSUPPORTED (-2) /* feature width outside the compiled range (f > 1024, or     */
@@ -144,6 +144,21 @@ int dfgnn_gt_bwd_stats(int m, int nnz, int h, int f, const int *row_ptr, const i
                        const float *Q, const float *K, const float *V, const float *row_max, const float *row_sum,
                        const float *grad_out, float *dQ, float *dK, float *dV, const int *plan, const int *plan_meta,
                        dfgnn_stream_t stream);
+/* The attn_edge pair with the attention values in RANK order (one head, unit edge values, dfgnn_gt_stats_applies == 1).
+ * attn_edge[h, nnz] between gt_hyper_forward and gt_backward is internal to FusedGTFunction_hyper
+ * (DFGNN/operators/fused_gtconv.py:79-158): all the pair needs is that both sides agree on an order.  Here the value of
+ * row i's k-th edge BY INCREASING COLUMN is stored at attn_ranked[row_ptr[i] + k] (fp32[nnz]): the forward then finds an
+ * edge's slot from the plan's bitmap (the number of set bits before it) instead of loading the edge list and building a
+ * position map, and the backward is dfgnn_gt_bwd's matrix-core kernel reading the plan's rank-ordered coordinates.  For
+ * rows whose columns are already increasing attn_ranked == attn_edge.  Results equal dfgnn_gt_hyper_fwd / dfgnn_gt_bwd
+ * (same arithmetic).  Other shapes: DFGNN_E_UNSUPPORTED. */
+int dfgnn_gt_hyper_fwd_ranked(int m, int nnz, int h, int f, const int *row_ptr, const int *col_ind, const float *Q,
+                              const float *K, const float *V, float *attn_ranked, float *out, const int *plan,
+                              const int *plan_meta, dfgnn_stream_t stream);
+int dfgnn_gt_bwd_ranked(int m, int nnz, int h, int f, const int *row_ptr, const int *col_ind, const float *Q,
+                        const float *K, const float *V, const float *attn_ranked, const float *grad_out, float *dQ,
+                        float *dK, float *dV, const int *plan, const int *plan_meta, dfgnn_stream_t stream);
+
 /* weights[256 i + c] = val[e] for the edge e from node i to the c-th node of i's range of the plan, 0 elsewhere:
  * dfgnn_plan_dense_weights_floats(m) = 256 m floats (device, 16-byte aligned), written by one memset + one kernel on
  * `stream`.  val: fp32[nnz] in CSR order.  Only the dense ranges of the plan are filled (dfgnn_gt_stats_applies == 1:

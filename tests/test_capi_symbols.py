@@ -30,7 +30,7 @@ def test_loader_signatures_cover_header():
                                                        "dfgnn_gat_tiling_chunked_ws_bytes", "dfgnn_plan_dense_weights_floats")]
     assert sorted(dfgnn_native.SIGNATURES) == compute
     lib = dfgnn_native.lib()
-    assert lib.dfgnn_abi_version() == 10
+    assert lib.dfgnn_abi_version() == 11
     assert b"bad argument" in lib.dfgnn_error_string(-1)
     assert b"unsupported" in lib.dfgnn_error_string(-2)
     assert lib.dfgnn_plan_ints(10, 40) >= 12 + 7 * 10 + 4 + 20 + 2 * 8 * 10  # header + lists + scratch (+ rocPRIM temporary storage) + edge coordinates + the two edge bitmaps
@@ -91,7 +91,7 @@ def test_torch_extension_binds_the_same_c_abi():
     assert "dfgnn_gt_hyper_fwd" in used and "dfgnn_gt_bwd" in used and "dfgnn_gat_softmax_fwd" in used
     assert set(used) <= set(_declared())
     ext = dfgnn_native.ext()
-    assert ext is not None and ext.abi_version() == 10 and ext.build_id() == dfgnn_native.source_hash()
+    assert ext is not None and ext.abi_version() == 11 and ext.build_id() == dfgnn_native.source_hash()
 
 
 def test_graft_entry_build_passes():
@@ -111,7 +111,7 @@ def test_library_opened_ahead_of_torch_brings_no_hip_runtime():
     code = ("import sys, ctypes; sys.path.insert(0, %r); import dfgnn_native as n; "
             "L = ctypes.CDLL(n.LIB_PATH); L.dfgnn_build_id.restype = ctypes.c_char_p; "
             "L.dfgnn_error_string.restype = ctypes.c_char_p; L.dfgnn_error_string.argtypes = [ctypes.c_int]; "
-            "assert L.dfgnn_abi_version() == 10 and L.dfgnn_build_id().decode() == n.source_hash() == n.build_id(); "
+            "assert L.dfgnn_abi_version() == 11 and L.dfgnn_build_id().decode() == n.source_hash() == n.build_id(); "
             "assert b'bad argument' in L.dfgnn_error_string(-1); "
             "maps = open('/proc/self/maps').read(); "
             "assert 'torch' not in sys.modules and 'libamdhip64' not in maps and 'libdfgnn_hip' not in maps, maps[-3000:]; "

@@ -138,6 +138,52 @@ def test_weighted_edges_on_the_matrix_cores(oracle_mod, h, f):
         assert torch.allclose(a, b, atol=5e-5, rtol=2e-4), what
 
 
+@pytest.mark.parametrize("f", [128, 64, 32, 16, 8])
+def test_ranked_pair_equals_the_attn_edge_pair(oracle_mod, f):
+    """The attn_edge pair with the values in rank order (dfgnn_gt_hyper_fwd_ranked / dfgnn_gt_bwd_ranked; one head): `out` and
+    the gradients are BIT-IDENTICAL to the CSR-ordered pair's (same arithmetic, another edge order in between), the values
+    are the CSR ones sorted by column within each row, everything agrees with the oracle, and FusedGTFunction_hyper takes
+    this pair at one head."""
+    import fused_gtconv as gt
+    from DFGNN.layers import preprocess_Hyper_fw_bw
+    from DFGNN.operators.fused_gtconv import GTConvFuse_hyper
+    from DFGNN.utils import synthetic as S
+    g = _geometry_batch(41 + f)
+    A, rows, row_ptr, col_ind, val, col_ptr, row_ind, val_idx, smem = preprocess_Hyper_fw_bw(g)
+    m, nnz = g.num_nodes(), g.num_edges()
+    Q, K, V = S.gt_features(m, 1, f, seed=7, device=DEV)
+    dO = torch.randn(m, 1, f, generator=torch.Generator().manual_seed(3)).to(DEV)
+    plan = gt.gt_ranked_pair_applies(row_ptr, col_ind, val, Q)
+    assert plan is not None and gt.gt_stats_pair_chosen(row_ptr, col_ind, val, Q) is None
+    out, attn_r = gt.gt_hyper_forward_ranked(row_ptr, col_ind, Q, K, V, plan=plan)
+    dQ, dK, dV = gt.gt_backward_ranked(row_ptr, col_ind, Q, K, V, attn_r, dO, plan=plan)
+    args = (row_ptr, col_ind, rows, val, col_ptr, row_ind, val_idx, smem, Q, K, V)
+    out_a, attn = gt.gt_hyper_forward(*args)
+    dQ_a, dK_a, dV_a = gt.gt_backward(*args, attn, dO)
+    assert torch.equal(out, out_a)
+    for a, b, what in ((dQ, dQ_a, "dQ"), (dK, dK_a, "dK"), (dV, dV_a, "dV")):
+        assert torch.equal(a, b), what
+    # rank order: row i's values sorted by column (the synthetic graphs' CSR rows are NOT column-sorted)
+    rp, ci = row_ptr.cpu().numpy(), col_ind.cpu().numpy().astype(np.int64)
+    row_of = np.repeat(np.arange(m), np.diff(rp))
+    order = np.lexsort((ci, row_of))                       # by row, then column
+    assert (order != np.arange(nnz)).any()
+    assert np.array_equal(attn_r.cpu().numpy().reshape(-1), attn.cpu().numpy().reshape(-1)[order])
+    n_ = lambda t: t.detach().cpu().numpy()  # noqa: E731
+    want = oracle_mod.gt_forward(rp, n_(col_ind), n_(val), n_(Q), n_(K), n_(V))
+    wq, wk, wv = oracle_mod.gt_backward(rp, n_(col_ind), n_(val), n_(Q), n_(K), n_(V), n_(dO))
+    _close(out, want, "out"); _close(dQ, wq, "dQ"); _close(dK, wk, "dK"); _close(dV, wv, "dV")
+    # the autograd function: same tensors through GTConvFuse_hyper
+    Qg, Kg, Vg = (t.clone().requires_grad_(True) for t in (Q, K, V))
+    o = GTConvFuse_hyper(rows, row_ptr, col_ind, val, col_ptr, row_ind, val_idx, smem, Qg, Kg, Vg)
+    o.backward(dO)
+    assert torch.equal(o.detach(), out) and torch.equal(Qg.grad, dQ) and torch.equal(Kg.grad, dK) and torch.equal(Vg.grad, dV)
+    # shapes the pair does not cover are refused, not computed differently
+    Q2 = S.gt_features(m, 2, f, seed=7, device=DEV)[0]
+    assert gt.gt_ranked_pair_applies(row_ptr, col_ind, val, Q2) is None
+    assert gt.gt_ranked_pair_applies(row_ptr, col_ind, torch.rand_like(val) + 0.5, Q) is None
+
+
 def test_plan_edge_bitmaps_equal_the_adjacency():
     """plan.hip: bit c of mask[8 i ..] <=> edge (i, n0 + c); bit r of maskT[8 j ..] <=> edge (n0 + r, j) -- for every
     node of every dense range, including the directed graphs (mask != maskT) and the isolated nodes (all zero)."""
@@ -156,7 +202,7 @@ def test_plan_edge_bitmaps_equal_the_adjacency():
     assert plan.num_dense == plan.num_fit and plan.num_spill == 0
     coords_off = plan.meta[11]
     mask_off = (coords_off + (nnz + 1) // 2 + 4 + 3) & ~3              # dfgnn_launch.hpp: plan_mask_off
-    assert mask_off + 16 * m + 4 == dfgnn_native.lib().dfgnn_plan_ints(m, nnz)
+    assert mask_off + 16 * m + (nnz + 1) // 2 + 4 == dfgnn_native.lib().dfgnn_plan_ints(m, nnz)   # bitmaps, ranked coordinates
     mask = buf[mask_off:mask_off + 8 * m].view(np.uint32).reshape(m, 8)
     maskT = buf[mask_off + 8 * m:mask_off + 16 * m].view(np.uint32).reshape(m, 8)
     fit = buf[12:12 + 2 * plan.num_fit].reshape(-1, 2)
@@ -359,7 +405,7 @@ def test_operator_runs_in_a_process_that_opened_the_library_before_torch(tmp_pat
 import ctypes, os, sys
 sys.path[:0] = [%(root)r, os.path.join(%(root)r, 'df-gnn_amd'), os.path.join(%(root)r, 'tests')]
 lib = ctypes.CDLL(os.path.join(%(root)r, 'df-gnn_amd', 'libdfgnn.so'))      # before torch
-assert lib.dfgnn_abi_version() == 10 and 'torch' not in sys.modules
+assert lib.dfgnn_abi_version() == 11 and 'torch' not in sys.modules
 import numpy as np, torch
 import oracle
 from DFGNN.layers import preprocess_Hyper_fw_bw

@@ -54,6 +54,10 @@ for n in (40, 107, 128, 140, 160, 175, 250):                  # every range clas
             o2, mx, sm = gt.gt_hyper_forward_stats(row_ptr, col_ind, Q, K, V)
             gt.gt_backward_stats(row_ptr, col_ind, Q, K, V, mx, sm, dO)
             launches += 2
+        if gt.gt_ranked_pair_applies(row_ptr, col_ind, val, Q) is not None:   # attn_edge pair in rank order (one head)
+            o3, attn_r = gt.gt_hyper_forward_ranked(row_ptr, col_ind, Q, K, V)
+            gt.gt_backward_ranked(row_ptr, col_ind, Q, K, V, attn_r, dO)
+            launches += 2
         if h == 1:                                                            # GAT training pair, with and without dropout
             ar, ac, X = S.gat_features(m, 1, f, seed=n, device=dev)
             for drop in (0.0, 0.3):

@@ -54,13 +54,14 @@ if what.startswith("gat_train"):
     torch.cuda.synchronize()
     print("done", what, iters, m, g.num_edges())
     sys.exit(0)
-if what == "pairs":  # both GT training pairs, fwd + bwd each (one profiled process covers all four dense kernels)
+if what == "pairs":  # the GT training pairs, fwd + bwd each, and the rank-ordered forward (one profiled process covers the five dense kernels)
     args = (row_ptr, col_ind, rows, val, col_ptr, row_ind, val_idx, smem, Q, K, V)
     for _ in range(iters):
         out, attn = gt.gt_hyper_forward(*args)
         gt.gt_backward(*args, attn, dO)
         out, rmax, rsum = gt.gt_hyper_forward_stats(row_ptr, col_ind, Q, K, V)
         gt.gt_backward_stats(row_ptr, col_ind, Q, K, V, rmax, rsum, dO)
+        out, attn_r = gt.gt_hyper_forward_ranked(row_ptr, col_ind, Q, K, V)
     torch.cuda.synchronize()
     print("done", what, iters, m, g.num_edges())
     sys.exit(0)
