@@ -8,6 +8,7 @@ timeout -k 10 400 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench r
 for h in 2 4 8; do timeout -k 10 200 python bench.py --heads $h --no-cpu-baseline --no-c4 > $O/bench_heads$h.json 2>/dev/null; done
 for h in 2 4 8; do DFGNN_STATS=0 timeout -k 10 200 python bench.py --heads $h --no-cpu-baseline --no-c4 > $O/bench_heads${h}_attn_pair.json 2>/dev/null; done
 DFGNN_STATS=1 timeout -k 10 200 python bench.py --no-cpu-baseline --no-c4 > $O/bench_stats_pair_h1.json 2>/dev/null
+DFGNN_RANKED=0 timeout -k 10 200 python bench.py --no-cpu-baseline --no-c4 > $O/bench_csr_order_pair_h1.json 2>/dev/null
 timeout -k 10 300 python tests/tools/bench_configs.py c2 c5 c3gat > $O/configs.jsonl 2>&1
 timeout -k 10 300 python tools/train_stack.py > $O/train_stack.jsonl 2>&1
 timeout -k 10 200 python tools/diag/class_bench_stats.py > $O/class_bench.txt 2>&1
