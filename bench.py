@@ -372,7 +372,7 @@ def main():
     attn_us = {"gt_hyper_fwd": ev_us(checked(fwd_call(VP)), reps), "gt_bwd": ev_us(checked(bwd_call(VP)), reps)}
     attn_bytes = algorithmic_bytes(m, nnz, h, f)
     # one head, all dense, unit values: the attn_edge pair in rank order is what the step launches
-    ranked_can = fused_gtconv.gt_ranked_pair_applies(W.row_ptr, W.col_ind, W.val, W.Q) if uses_stats is None else None
+    ranked_can = fused_gtconv.gt_ranked_pair_chosen(W.row_ptr, W.col_ind, W.val, W.Q)
     ranked_us = None
     if ranked_can is not None:
         ranked_us = {

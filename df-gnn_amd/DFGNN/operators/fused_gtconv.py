@@ -40,7 +40,7 @@ class FusedGTFunction_hyper(torch.autograd.Function):
             out_feat, row_max, row_sum = fused_gt.gt_hyper_forward_stats(row_ptr, col_ind, Q, K, V, ctx.stats, val)
             ctx.save_for_backward(row_ptr, col_ind, Q, K, V, row_max, row_sum, val)
             return out_feat
-        ctx.ranked = fused_gt.gt_ranked_pair_applies(row_ptr, col_ind, val, Q)   # the block plan, or None
+        ctx.ranked = fused_gt.gt_ranked_pair_chosen(row_ptr, col_ind, val, Q)   # the block plan, or None
         if ctx.ranked is not None:   # one head, all dense, unit values: attn_edge in rank order (same pair, cheaper forward)
             out_feat, attn_ranked = fused_gt.gt_hyper_forward_ranked(row_ptr, col_ind, Q, K, V, ctx.ranked)
             ctx.save_for_backward(row_ptr, col_ind, Q, K, V, attn_ranked)

@@ -175,6 +175,11 @@ class BlockPlan:
         """Fit ranges marked for the matrix-core kernels (they come first in the list)."""
         return self.meta[9]
 
+    @property
+    def num_dense_wide(self):
+        """... of which this many have more than 128 nodes (a batch without any takes the 256-thread forward kernels)."""
+        return self.meta[10]
+
     def ptrs(self):
         import ctypes
         return self.buf.data_ptr(), ctypes.addressof(self._meta_c)

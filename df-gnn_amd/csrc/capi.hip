@@ -202,14 +202,14 @@ int dfgnn_gt_bwd_stats(int m, int nnz, int h, int f, const int *row_ptr, const i
   return launch_gt_dense_bwd_stats(g, p, Q, K, V, row_max, row_sum, grad_out, dQ, dK, dV, as_stream(stream));
 }
 
-// the attn_edge pair in rank order (one head, all-dense plan, unit edge values)
+// the attn_edge pair in rank order (all-dense plan, unit edge values)
 int dfgnn_gt_hyper_fwd_ranked(int m, int nnz, int h, int f, const int *row_ptr, const int *col_ind, const float *Q,
                               const float *K, const float *V, float *attn_ranked, float *out, const int *plan,
                               const int *plan_meta, dfgnn_stream_t stream) {
   if (int c = check_common(m, nnz, h, f, row_ptr, col_ind)) return c < 0 ? c : 0;
   if (!Q || !K || !V || !out || !attn_ranked) return kErrBadArg;
   Plan p;
-  if (h != 1 || !(aligned16(Q) && aligned16(K) && aligned16(V) && aligned16(out)) || !gt_stats_plan(p, plan, plan_meta, m, nnz, h, f))
+  if (!(aligned16(Q) && aligned16(K) && aligned16(V) && aligned16(out)) || !gt_stats_plan(p, plan, plan_meta, m, nnz, h, f))
     return kErrUnsupported;
   const Csr g{m, nnz, h, f, row_ptr, col_ind, nullptr, nullptr};
   return launch_gt_dense_fwd_ranked(g, p, Q, K, V, attn_ranked, out, as_stream(stream));
@@ -221,7 +221,7 @@ int dfgnn_gt_bwd_ranked(int m, int nnz, int h, int f, const int *row_ptr, const 
   if (int c = check_common(m, nnz, h, f, row_ptr, col_ind)) return c < 0 ? c : 0;
   if (!Q || !K || !V || !attn_ranked || !grad_out || !dQ || !dK || !dV) return kErrBadArg;
   Plan p;
-  if (h != 1 || !(aligned16(Q) && aligned16(K) && aligned16(V) && aligned16(grad_out) && aligned16(dQ) && aligned16(dK) && aligned16(dV)) ||
+  if (!(aligned16(Q) && aligned16(K) && aligned16(V) && aligned16(grad_out) && aligned16(dQ) && aligned16(dK) && aligned16(dV)) ||
       !gt_stats_plan(p, plan, plan_meta, m, nnz, h, f))
     return kErrUnsupported;
   const Csr g{m, nnz, h, f, row_ptr, col_ind, nullptr, nullptr};

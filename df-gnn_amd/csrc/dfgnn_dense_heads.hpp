@@ -61,7 +61,8 @@ __device__ __forceinline__ void dense_fwd_heads_body(float *lds, int lds_bytes, 
                                                      const float *__restrict__ V, float *__restrict__ attn_edge,
                                                      float *__restrict__ out, float *__restrict__ stat_max = nullptr,
                                                      float *__restrict__ stat_sum = nullptr) {
-  static_assert(!(STATS && WRITE_ATTN), "the statistics-saving forward writes no attention values");
+  // STATS && WRITE_ATTN: the rank-ordered training forward (see dense_fwd_body): the map words hold RANKS -- the position of a
+  // pair among the set bits of its row's bitmap -- and the values go out at row_ptr[i] + rank
   constexpr int FW = kHeadsGroupWidth, G = FW / FR, NT = NP / 16, KTH = FR == 64 ? 2 : 1, FTH = FR / 16;
   using D = DenseCfg<FW>;
   constexpr int RS = D::RS, KT = D::KT, FT = D::FT;
@@ -182,7 +183,17 @@ __device__ __forceinline__ void dense_fwd_heads_body(float *lds, int lds_bytes, 
     const unsigned char *mrow = map + min(i, nstrip * 16 - 1) * MS + 4 * L.mq;
 #pragma unroll
     for (int jt = 0; jt < NT; ++jt) {
-      if constexpr (STATS) {
+      if constexpr (STATS && WRITE_ATTN) {
+        const unsigned word = mbits[s][STATS ? jt / 2 : 0], low = 16u * (jt & 1) + 4u * L.mq;
+        const unsigned b4 = (i < n && jt < ntile) ? (word >> low) & 0xFu : 0u;
+        unsigned before = 0;  // set bits of the row's earlier words
+#pragma unroll
+        for (int v = 0; v < jt / 2; ++v) before += __popc(mbits[s][STATS ? v : 0]);
+        const unsigned r0 = before + __popc(word & ((1u << low) - 1u));
+        const unsigned r1 = r0 + (b4 & 1u), r2 = r1 + ((b4 >> 1) & 1u), r3 = r2 + ((b4 >> 2) & 1u);
+        mw[s][jt] = ((b4 & 1u) ? r0 : 0xFFu) | (((b4 & 2u) ? r1 : 0xFFu) << 8) | (((b4 & 4u) ? r2 : 0xFFu) << 16) |
+                    (((b4 & 8u) ? r3 : 0xFFu) << 24);
+      } else if constexpr (STATS) {
         const unsigned b = (i < n && jt < ntile) ? (mbits[s][STATS ? jt / 2 : 0] >> (16 * (jt & 1) + 4 * L.mq)) & 0xFu : 0u;
         // bit r -> byte r: 0x00 where the bit is set, 0xFF where it is not
         mw[s][jt] = ~(((b & 1u) | ((b & 2u) << 7) | ((b & 4u) << 14) | ((b & 8u) << 21)) * 0xFFu);
@@ -194,6 +205,10 @@ __device__ __forceinline__ void dense_fwd_heads_body(float *lds, int lds_bytes, 
       row_e0[s] = rp[min(i, n)];
       strip_e0[s] = rp[min(n, strip * 16)];
       strip_e1[s] = rp[min(n, strip * 16 + 16)];
+    } else if constexpr (WRITE_ATTN) {  // (no row_ptr copy in LDS here: three loads per strip)
+      row_e0[s] = g.row_ptr[n0 + min(i, n)] - e0;
+      strip_e0[s] = g.row_ptr[n0 + min(n, strip * 16)] - e0;
+      strip_e1[s] = g.row_ptr[n0 + min(n, strip * 16 + 16)] - e0;
     }
   }
 
@@ -286,7 +301,7 @@ __device__ __forceinline__ void dense_fwd_heads_body(float *lds, int lds_bytes, 
           const float inv = (sum != 0.f) ? 1.f / sum : 0.f;
           if constexpr (STATS) {
             const int i = strip * 16 + L.mi;
-            if (i < n && L.mq == 0) {
+            if (stat_max && i < n && L.mq == 0) {
               stat_max[(size_t)(n0 + i) * g.h + head] = (mx == -INFINITY) ? -1e38f : mx * (ksc.inv * qinv);
               stat_sum[(size_t)(n0 + i) * g.h + head] = sum;
             }

@@ -19,6 +19,7 @@
 #define DFGNN_RING160 2
 #endif
 #include "dfgnn_dense_wide.hpp"
+#include "dfgnn_dense_heads.hpp"
 #include "dfgnn_dense_fwd.hpp"
 #include "dfgnn_dense_bwd.hpp"
 #include "dfgnn_dense_bwd_rc2.hpp"
@@ -69,7 +70,7 @@ __global__ __launch_bounds__(kDenseThreads) void gt_dense_bwd_stats_w_kernel(
     dense_bwd_body<F, kDenseChunkRows, 2, false, true, true>(lds, g, n0, n, 0, 0, head, Q, K, V, nullptr, dO, dQ, dK, dV, st);
 }
 
-// ---- the "ranked" training forward (one head): attn_edge written, but in RANK order -------------------------------------
+// ---- the "ranked" training forward: attn_edge written, but in RANK order -------------------------------------
 // The attn_edge pair's forward spends a fifth of its time on the sparse structure: 2 B of coordinates per edge, a byte map
 // (cleared, scattered into, read back) to find an edge's CSR position.  What the autograd pair needs is only that forward
 // and backward agree on an order -- so this forward takes the edges from the bitmaps like the statistics forward and
@@ -87,12 +88,46 @@ __global__ __launch_bounds__(kDenseThreads) void gt_dense_fwd_ranked_kernel(Csr 
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int n0 = fit[2 * blockIdx.x], n1 = fit[2 * blockIdx.x + 1] & kPlanRangeMask;
   const int n = n1 - n0, e0 = g.row_ptr[n0], ne = g.row_ptr[n1] - e0;
+  // (the three classes as non-inlined functions -- each then keeps its own register allocation, 170 / 192 / 236 VGPRs and no
+  // spills instead of 256 and 19 for the merged body -- ran 84 -> 102 us: behind a call the LDS pointers are generic and
+  // every ds_ access becomes a flat one)
   if (n <= kDenseChunkRows)
     dense_fwd_body<F, true, 1, kDenseChunkRows, 1, false, false, true>(lds, lds_bytes, g, n0, n, e0, ne, 0, 1, Q, K, V, attn_ranked, out);
   else if (n <= kDenseWideRows)
     dense_fwd_body<F, true, 2, kDenseWideRows, 1, false, false, true>(lds, lds_bytes, g, n0, n, e0, ne, 0, 1, Q, K, V, attn_ranked, out);
+#ifndef DFGNN_RANKED_NO_TWO_CHUNK  // (diagnostic builds: what the rare > 160-node class costs the others in registers)
   else
     dense_fwd_body<F, true, 2, kDenseChunkRows, 2, false, false, true>(lds, lds_bytes, g, n0, n, e0, ne, 0, 1, Q, K, V, attn_ranked, out);
+#endif
+}
+
+// ... several heads: every head of the range in this workgroup, like gt_dense_fwd_kernel (a kernel of its own: its widest
+// body must not set the register budget of the one-head kernel above)
+template <int F>
+__global__ __launch_bounds__(kDenseThreads) void gt_dense_fwd_ranked_heads_kernel(Csr g, const int *__restrict__ fit,
+                                                                                  const float *__restrict__ Q,
+                                                                                  const float *__restrict__ K,
+                                                                                  const float *__restrict__ V,
+                                                                                  float *__restrict__ attn_ranked,
+                                                                                  float *__restrict__ out, int lds_bytes) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int n0 = fit[2 * blockIdx.x], n1 = fit[2 * blockIdx.x + 1] & kPlanRangeMask;
+  const int n = n1 - n0, e0 = g.row_ptr[n0], ne = g.row_ptr[n1] - e0;
+  if constexpr (F == 16 || F == 32 || F == 64) {
+    if (dense_heads_ok(F, g.h) && n <= kDenseWideRows) {  // heads in groups of 64 columns (dfgnn_dense_heads.hpp)
+      if (n <= kDenseChunkRows)
+        dense_fwd_heads_body<F, true, 1, kDenseChunkRows, true>(lds, lds_bytes, g, n0, n, e0, ne, Q, K, V, attn_ranked, out);
+      else
+        dense_fwd_heads_body<F, true, 2, kDenseWideRows, true>(lds, lds_bytes, g, n0, n, e0, ne, Q, K, V, attn_ranked, out);
+      return;
+    }
+  }
+  if (n <= kDenseChunkRows)
+    dense_fwd_body<F, true, 1, kDenseChunkRows, 1, false, true, true>(lds, lds_bytes, g, n0, n, e0, ne, 0, g.h, Q, K, V, attn_ranked, out);
+  else if (n <= kDenseWideRows)
+    dense_fwd_body<F, true, 2, kDenseWideRows, 1, false, true, true>(lds, lds_bytes, g, n0, n, e0, ne, 0, g.h, Q, K, V, attn_ranked, out);
+  else
+    dense_fwd_body<F, true, 2, kDenseChunkRows, 2, false, true, true>(lds, lds_bytes, g, n0, n, e0, ne, 0, g.h, Q, K, V, attn_ranked, out);
 }
 
 template <class Fn>
@@ -138,8 +173,13 @@ int launch_gt_dense_fwd_ranked(const Csr &g_in, const Plan &p, const float *Q, c
   const dim3 grid(p.num_dense, 1);
   return dispatch_dense_w(g.f, [&](auto fc) {
     constexpr int F = decltype(fc)::value;
-    if (int rc = set_max_lds_cached(gt_dense_fwd_ranked_kernel<F>)) return rc;
-    gt_dense_fwd_ranked_kernel<F><<<grid, kDenseThreads, kLdsBytes, s>>>(g, p.fit(), Q, K, V, attn_ranked, out, kLdsBytes);
+    if (g.h == 1) {
+      if (int rc = set_max_lds_cached(gt_dense_fwd_ranked_kernel<F>)) return rc;
+      gt_dense_fwd_ranked_kernel<F><<<grid, kDenseThreads, kLdsBytes, s>>>(g, p.fit(), Q, K, V, attn_ranked, out, kLdsBytes);
+    } else {
+      if (int rc = set_max_lds_cached(gt_dense_fwd_ranked_heads_kernel<F>)) return rc;
+      gt_dense_fwd_ranked_heads_kernel<F><<<grid, kDenseThreads, kLdsBytes, s>>>(g, p.fit(), Q, K, V, attn_ranked, out, kLdsBytes);
+    }
     return launch_status();
   });
 }

@@ -153,6 +153,10 @@ def gt_backward(row_ptr, col_ind, rows, val, col_ptr, row_ind, val_idx, smem_con
 _STATS_ENV = os.environ.get("DFGNN_STATS", "auto")
 USE_STATS_PAIR = _STATS_ENV != "0"
 STATS_PAIR_MIN_HEADS = 1 if _STATS_ENV == "1" else 2
+# the attn_edge pair in rank order (further down): DFGNN_RANKED=0 switches it off, DFGNN_RANKED_HEADS lists the head counts
+# it is taken at (default: one head)
+USE_RANKED_PAIR = os.environ.get("DFGNN_RANKED", "1") != "0"
+RANKED_HEADS = tuple(int(x) for x in os.environ.get("DFGNN_RANKED_HEADS", "1").split(",") if x)
 
 
 def gt_stats_pair_applies(row_ptr, col_ind, val, Q):
@@ -174,6 +178,8 @@ def gt_stats_pair_chosen(row_ptr, col_ind, val, Q):
     no matrix-core form for them."""
     if Q.dim() != 3 or (Q.size(1) < STATS_PAIR_MIN_HEADS and val_ptr(val) is None):
         return None
+    if _STATS_ENV != "1" and Q.size(1) in RANKED_HEADS and gt_ranked_pair_chosen(row_ptr, col_ind, val, Q) is not None:
+        return None     # (a head count handed to the rank-ordered attn_edge pair: DFGNN_RANKED_HEADS)
     return gt_stats_pair_applies(row_ptr, col_ind, val, Q)
 
 
@@ -188,15 +194,27 @@ def _stats_weights(plan, row_ptr, val):
 # What FusedGTFunction_hyper takes at ONE head on an all-dense batch with unit edge values: the attention values travel from
 # forward to backward like in the reference, but ordered by column within a row, which lets the forward find an edge's slot
 # from the plan's bitmap instead of the edge list (csrc/gt_dense_stats_w.hip: gt_dense_fwd_ranked_kernel).
-USE_RANKED_PAIR = os.environ.get("DFGNN_RANKED", "1") != "0"
 
 
 def gt_ranked_pair_applies(row_ptr, col_ind, val, Q):
     """The block plan when gt_hyper_forward_ranked / gt_backward_ranked can serve this call, else None."""
-    if not (USE_RANKED_PAIR and USE_BLOCK_PLAN) or Q.dim() != 3 or not Q.is_cuda or Q.size(1) != 1 or val_ptr(val) is not None:
+    if not (USE_RANKED_PAIR and USE_BLOCK_PLAN) or Q.dim() != 3 or not Q.is_cuda or val_ptr(val) is not None:
         return None
     plan = get_plan_obj(row_ptr, col_ind, Q.size(-1), True)
-    if plan is not None and plan.stats_applies(1):
+    if plan is not None and plan.stats_applies(Q.size(1)):
+        return plan
+    return None
+
+
+def gt_ranked_pair_chosen(row_ptr, col_ind, val, Q):
+    """gt_ranked_pair_applies under the measured policy: at one head, for batches that hold a range of more than 128
+    nodes (C3: forward 97 -> 84 us).  A one-head batch without any has the CSR-ordered pair's 256-thread forward, two
+    workgroups per CU, which is the faster one there (107-node graphs: 74 against 78 us); RANKED_HEADS widens the head
+    counts (DFGNN_RANKED_HEADS=1,2,4)."""
+    if Q.dim() != 3 or Q.size(1) not in RANKED_HEADS:
+        return None
+    plan = gt_ranked_pair_applies(row_ptr, col_ind, val, Q)
+    if plan is not None and (Q.size(1) > 1 or plan.num_dense_wide > 0 or Q.size(-1) not in (64, 128)):
         return plan
     return None
 
@@ -256,7 +274,7 @@ def gt_hyper_step_raw(row_ptr, col_ind, rows, val, col_ptr, row_ind, val_idx, sm
     if plan is not None:
         out, rmax, rsum = gt_hyper_forward_stats(row_ptr, col_ind, Q, K, V, plan=plan, val=val)
         return [out] + list(gt_backward_stats(row_ptr, col_ind, Q, K, V, rmax, rsum, grad, plan=plan, val=val))
-    plan = gt_ranked_pair_applies(row_ptr, col_ind, val, Q)
+    plan = gt_ranked_pair_chosen(row_ptr, col_ind, val, Q)
     if plan is not None:
         out, attn = gt_hyper_forward_ranked(row_ptr, col_ind, Q, K, V, plan=plan)
         return [out] + list(gt_backward_ranked(row_ptr, col_ind, Q, K, V, attn, grad, plan=plan))

@@ -153,7 +153,7 @@ def test_ranked_pair_equals_the_attn_edge_pair(oracle_mod, f):
     m, nnz = g.num_nodes(), g.num_edges()
     Q, K, V = S.gt_features(m, 1, f, seed=7, device=DEV)
     dO = torch.randn(m, 1, f, generator=torch.Generator().manual_seed(3)).to(DEV)
-    plan = gt.gt_ranked_pair_applies(row_ptr, col_ind, val, Q)
+    plan = gt.gt_ranked_pair_chosen(row_ptr, col_ind, val, Q)     # (the batch holds ranges of more than 128 nodes)
     assert plan is not None and gt.gt_stats_pair_chosen(row_ptr, col_ind, val, Q) is None
     out, attn_r = gt.gt_hyper_forward_ranked(row_ptr, col_ind, Q, K, V, plan=plan)
     dQ, dK, dV = gt.gt_backward_ranked(row_ptr, col_ind, Q, K, V, attn_r, dO, plan=plan)
@@ -178,10 +178,39 @@ def test_ranked_pair_equals_the_attn_edge_pair(oracle_mod, f):
     o = GTConvFuse_hyper(rows, row_ptr, col_ind, val, col_ptr, row_ind, val_idx, smem, Qg, Kg, Vg)
     o.backward(dO)
     assert torch.equal(o.detach(), out) and torch.equal(Qg.grad, dQ) and torch.equal(Kg.grad, dK) and torch.equal(Vg.grad, dV)
-    # shapes the pair does not cover are refused, not computed differently
-    Q2 = S.gt_features(m, 2, f, seed=7, device=DEV)[0]
-    assert gt.gt_ranked_pair_applies(row_ptr, col_ind, val, Q2) is None
+    # edge values: not this pair's (they go to the statistics pair)
     assert gt.gt_ranked_pair_applies(row_ptr, col_ind, torch.rand_like(val) + 0.5, Q) is None
+
+
+@pytest.mark.parametrize("h,f", [(2, 64), (4, 32), (8, 16), (3, 32), (2, 128), (2, 8)])
+def test_ranked_pair_several_heads(oracle_mod, h, f):
+    """The rank-ordered pair with several heads (every head of a range in one workgroup in the forward): bit-identical to
+    the CSR-ordered pair, values sorted by column within each row per head."""
+    import fused_gtconv as gt
+    from DFGNN.layers import preprocess_Hyper_fw_bw
+    from DFGNN.utils import synthetic as S
+    g = _geometry_batch(43 + f)
+    A, rows, row_ptr, col_ind, val, col_ptr, row_ind, val_idx, smem = preprocess_Hyper_fw_bw(g)
+    m, nnz = g.num_nodes(), g.num_edges()
+    Q, K, V = S.gt_features(m, h, f, seed=7, device=DEV)
+    dO = torch.randn(m, h, f, generator=torch.Generator().manual_seed(3)).to(DEV)
+    plan = gt.gt_ranked_pair_applies(row_ptr, col_ind, val, Q)
+    assert plan is not None
+    out, attn_r = gt.gt_hyper_forward_ranked(row_ptr, col_ind, Q, K, V, plan=plan)
+    dQ, dK, dV = gt.gt_backward_ranked(row_ptr, col_ind, Q, K, V, attn_r, dO, plan=plan)
+    args = (row_ptr, col_ind, rows, val, col_ptr, row_ind, val_idx, smem, Q, K, V)
+    out_a, attn = gt.gt_hyper_forward(*args)
+    dQ_a, dK_a, dV_a = gt.gt_backward(*args, attn, dO)
+    assert torch.equal(out, out_a)
+    for a, b, what in ((dQ, dQ_a, "dQ"), (dK, dK_a, "dK"), (dV, dV_a, "dV")):
+        assert torch.equal(a, b), what
+    rp, ci = row_ptr.cpu().numpy(), col_ind.cpu().numpy().astype(np.int64)
+    order = np.lexsort((ci, np.repeat(np.arange(m), np.diff(rp))))
+    assert np.array_equal(attn_r.cpu().numpy(), attn.cpu().numpy()[:, order])
+    n_ = lambda t: t.detach().cpu().numpy()  # noqa: E731
+    wq, wk, wv = oracle_mod.gt_backward(rp, n_(col_ind), n_(val), n_(Q), n_(K), n_(V), n_(dO))
+    _close(out, oracle_mod.gt_forward(rp, n_(col_ind), n_(val), n_(Q), n_(K), n_(V)), "out")
+    _close(dQ, wq, "dQ"); _close(dK, wk, "dK"); _close(dV, wv, "dV")
 
 
 def test_plan_edge_bitmaps_equal_the_adjacency():
@@ -255,9 +284,10 @@ def test_autograd_function_takes_the_stats_pair_when_it_applies(oracle_mod, monk
     assert taken == ["stats"] * 3
     run(_geometry_batch(1, duplicate=True), weighted=True)   # not all dense: the edge-walking kernels
     assert taken == ["stats"] * 3
-    run(_geometry_batch(1), heads=1)                  # one head: the attn_edge pair is the faster one (the policy's choice)
+    run(_geometry_batch(1), heads=1)                  # one head: the attn_edge pair (in rank order) is the faster one
     assert taken == ["stats"] * 3
     monkeypatch.setattr(gt, "STATS_PAIR_MIN_HEADS", 1)  # (DFGNN_STATS=1)
+    monkeypatch.setattr(gt, "_STATS_ENV", "1")
     run(_geometry_batch(1), heads=1)
     assert taken == ["stats"] * 4
     monkeypatch.setattr(gt, "USE_STATS_PAIR", False)
