@@ -379,7 +379,16 @@ __device__ __forceinline__ void dense_fwd_body(float *lds, int lds_bytes, const 
           wave_sync();
           const int s0 = rp[strip * 16], s1 = rp[min(n, strip * 16 + 16)];
           float *dst = attn_edge + (size_t)hd * g.nnz + e0;
-          for (int e = s0 + (int)(threadIdx.x & (kWave - 1)); e < s1; e += kWave) dst[e] = pstage[e];
+          // four lines per trip: the LDS reads of a trip are issued together (one read -> one store per trip is a chain of
+          // LDS round trips: 13 of them for a strip of 830 edges)
+          for (int e = s0 + (int)(threadIdx.x & (kWave - 1)); e < s1; e += 4 * kWave) {
+            float v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = pstage[min(e + k * kWave, s1 - 1)];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+              if (e + k * kWave < s1) dst[e + k * kWave] = v[k];
+          }
         }
       }
     }

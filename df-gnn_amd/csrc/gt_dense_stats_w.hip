@@ -78,6 +78,9 @@ __global__ __launch_bounds__(kDenseThreads) void gt_dense_bwd_stats_w_kernel(
 // it), and gt_dense_bwd_kernel reads the values back with the plan's rank-ordered coordinates instead of the CSR-ordered
 // ones: the backward is the same kernel at the same cost.  gt_hyper_forward -> [out, attn_edge] for direct callers keeps
 // the CSR order (gt_dense_fwd_kernel).
+#ifndef DFGNN_RANKED_WRITE
+#define DFGNN_RANKED_WRITE true  // (diagnostic builds: false = the same kernel without the attention values, for phase stamps)
+#endif
 template <int F>
 __global__ __launch_bounds__(kDenseThreads) void gt_dense_fwd_ranked_kernel(Csr g, const int *__restrict__ fit,
                                                                             const float *__restrict__ Q,
@@ -92,12 +95,12 @@ __global__ __launch_bounds__(kDenseThreads) void gt_dense_fwd_ranked_kernel(Csr 
   // spills instead of 256 and 19 for the merged body -- ran 84 -> 102 us: behind a call the LDS pointers are generic and
   // every ds_ access becomes a flat one)
   if (n <= kDenseChunkRows)
-    dense_fwd_body<F, true, 1, kDenseChunkRows, 1, false, false, true>(lds, lds_bytes, g, n0, n, e0, ne, 0, 1, Q, K, V, attn_ranked, out);
+    dense_fwd_body<F, DFGNN_RANKED_WRITE, 1, kDenseChunkRows, 1, false, false, true>(lds, lds_bytes, g, n0, n, e0, ne, 0, 1, Q, K, V, attn_ranked, out);
   else if (n <= kDenseWideRows)
-    dense_fwd_body<F, true, 2, kDenseWideRows, 1, false, false, true>(lds, lds_bytes, g, n0, n, e0, ne, 0, 1, Q, K, V, attn_ranked, out);
+    dense_fwd_body<F, DFGNN_RANKED_WRITE, 2, kDenseWideRows, 1, false, false, true>(lds, lds_bytes, g, n0, n, e0, ne, 0, 1, Q, K, V, attn_ranked, out);
 #ifndef DFGNN_RANKED_NO_TWO_CHUNK  // (diagnostic builds: what the rare > 160-node class costs the others in registers)
   else
-    dense_fwd_body<F, true, 2, kDenseChunkRows, 2, false, false, true>(lds, lds_bytes, g, n0, n, e0, ne, 0, 1, Q, K, V, attn_ranked, out);
+    dense_fwd_body<F, DFGNN_RANKED_WRITE, 2, kDenseChunkRows, 2, false, false, true>(lds, lds_bytes, g, n0, n, e0, ne, 0, 1, Q, K, V, attn_ranked, out);
 #endif
 }
 
