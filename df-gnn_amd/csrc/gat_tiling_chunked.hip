@@ -71,6 +71,47 @@ __device__ __forceinline__ void gat_segment_online(int eb, int ee, const short *
   }
 }
 
+// The same with the FIRST tile's column offsets (c0: this lane's edge of the tile, -1 = none) and attn_col values (a0)
+// already in registers: the kernel below fetches them one / two segments ahead (seg_ptr -> ccol -> attn_col -> X is a chain
+// of four dependent memory round trips per segment, and a segment is ~30 edges: without the look-ahead the chain, not the
+// gather rate, is what a wave's time is made of).
+template <class C>
+__device__ __forceinline__ void gat_segment_online_pre(int eb, int ee, int c0, float a0, const short *__restrict__ ccol, int col0,
+                                                       float ar, const float *__restrict__ attn_col_h, int h, float slope,
+                                                       const float *__restrict__ Xh, size_t hf, int f, float *sw, int *sc,
+                                                       float *__restrict__ pmax, float *__restrict__ psum,
+                                                       float *__restrict__ pacc, int lane) {
+  const int gid = lane / C::G, gl = lane % C::G;
+  Frag<C> acc;
+  frag_zero<C>(acc);
+  float m_run = -INFINITY, l_run = 0.f;
+  for (int t0 = eb; t0 < ee; t0 += kWave) {
+    const int nt = min(kWave, ee - t0);
+    float s = -INFINITY;
+    int c = col0;
+    if (t0 == eb) {  // (wave-uniform)
+      if (lane < nt) {
+        c = col0 + c0;
+        s = leaky_relu(ar + a0, slope);
+      }
+    } else if (lane < nt) {
+      c = col0 + (int)ccol[t0 + lane];
+      s = leaky_relu(ar + attn_col_h[(size_t)c * h], slope);
+    }
+    sc[lane] = c;
+    online_step<C>(s, lane, sw, acc, m_run, l_run);
+    wave_sync();
+    spmm_accum<C>(acc, sw, sc, nt, Xh, hf, f, gid, gl);
+    wave_sync();
+  }
+  frag_reduce_groups<C>(acc);
+  if (gid == 0) frag_store_scaled<C>(acc, 1.f, pacc, f, gl);
+  if (lane == 0) {
+    *pmax = m_run;
+    *psum = l_run;
+  }
+}
+
 template <class C>
 __global__ __launch_bounds__(kBlock) void gat_chunk_partial_kernel(ChunkGraph g, const float *__restrict__ attn_row,
                                                                    const float *__restrict__ attn_col, float slope,
@@ -101,13 +142,43 @@ __global__ __launch_bounds__(kBlock) void gat_chunk_partial_kernel(ChunkGraph g,
       const float *Xh = X + (size_t)head * g.f, *acol_h = attn_col + head;
       const int *sp = g.seg_ptr + (size_t)chunk * g.m;
       const int r_end = min(g.m, (rb + 1) * kChunkItemRows);
-      for (int r = rb * kChunkItemRows + wave; r < r_end; r += kWavesPerBlock) {
-        const int eb = sp[r], ee = sp[r + 1];
+      // this wave's rows of the item: rbase + kWavesPerBlock k, k < NR.  Their segment bounds and attn_row values come with
+      // ONE load each (lane l < NR: seg_ptr[r_l], lane NR + l: seg_ptr[r_l + 1]; rows past the end read as empty), the
+      // first tile's column offsets are fetched two segments ahead and its attn_col values one segment ahead.
+      constexpr int NR = kChunkItemRows / kWavesPerBlock;
+      static_assert(2 * NR <= kWave, "segment bounds of a wave's rows in one load");
+      const int rbase = rb * kChunkItemRows + wave;
+      int spv = 0;
+      float arv = 0.f;
+      {
+        const int rr = rbase + kWavesPerBlock * (lane & (NR - 1));
+        const bool ok = rr < r_end && lane < 2 * NR;
+        spv = ok ? sp[rr + (lane >= NR ? 1 : 0)] : 0;
+        if (lane < NR) arv = (rr < r_end) ? attn_row[(size_t)rr * g.h + head] : 0.f;
+      }
+      const int col0 = chunk * g.chunk_rows;
+      auto first_cols = [&](int k) -> int {  // this lane's column offset in the first tile of segment k, -1 = none
+        if (k >= NR) return -1;
+        const int eb = __builtin_amdgcn_readlane(spv, k), ee = __builtin_amdgcn_readlane(spv, NR + k);
+        return (lane < min(kWave, ee - eb)) ? (int)g.ccol[eb + lane] : -1;
+      };
+      auto first_attn = [&](int c) -> float { return (c >= 0) ? acol_h[(size_t)(col0 + c) * g.h] : 0.f; };
+      int c0 = first_cols(0), c1 = first_cols(1);
+      float a0 = first_attn(c0);
+      for (int k = 0; k < NR; ++k) {
+        const int c2 = first_cols(k + 2);
+        const float a1 = first_attn(c1);
+        const int eb = __builtin_amdgcn_readlane(spv, k), ee = __builtin_amdgcn_readlane(spv, NR + k);
         if (ee > eb) {  // (empty segments keep the zero the launcher's memset put into psum)
+          const int r = rbase + kWavesPerBlock * k;
           const size_t slot = ((size_t)head * g.nchunks + chunk) * g.m + r;
-          gat_segment_online<C>(eb, ee, g.ccol, chunk * g.chunk_rows, attn_row[(size_t)r * g.h + head], acol_h, g.h, slope, Xh,
-                                hf, g.f, sw, sc, pmax + slot, psum + slot, pacc + slot * g.f, lane);
+          const float ar = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, arv), k));
+          gat_segment_online_pre<C>(eb, ee, c0, a0, g.ccol, col0, ar, acol_h, g.h, slope, Xh, hf, g.f, sw, sc, pmax + slot,
+                                    psum + slot, pacc + slot * g.f, lane);
         }
+        c0 = c1;
+        a0 = a1;
+        c1 = c2;
       }
     }
   }
