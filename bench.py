@@ -260,11 +260,18 @@ def main():
         """`warmup` untimed steps, then exactly `steps` timed ones between barriers (barrier = device synchronise + process
         barrier).  The collector is held off for the timed steps: a collection pass in a 13 ms region shows up as +10 %."""
         import gc
+        late = os.environ.get("DFGNN_BENCH_GC_LATE") == "1"   # (A/B switch: the collection pass between warm-up and timing)
+        if not late:
+            # the collection pass goes BEFORE the warm-up steps: it takes tens of milliseconds of host time, and with the device
+            # idle that long the first timed steps run at ramping clocks (seen as +3..4 % on a 20-step region)
+            gc.collect()
+            gc.disable()
         for _ in range(warmup):
             w.step()
         barrier()
-        gc.collect()
-        gc.disable()
+        if late:
+            gc.collect()
+            gc.disable()
         try:
             t0 = time.perf_counter()
             for _ in range(steps):
