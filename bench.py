@@ -45,7 +45,7 @@ import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md; ~6.3 TB/s is the measured copy rate)
 PMC_PROFILE = os.path.join("profiles", "r03_pmc_dense_kernels.json")  # HBM bytes per launch from rocprofv3 --pmc passes
-SETUP_STEPS = 20  # untimed steps inside Workload(): plan build, allocator pools, clocks (reported as "setup_steps")
+SETUP_STEPS = 40  # untimed steps inside Workload(): plan build, allocator pools, device clocks (~10 ms of continuous work; reported as "setup_steps")
 
 
 def parse():
@@ -147,6 +147,8 @@ class Workload:
         # part of setting the workload up, like the preprocessing above: the first call builds the block plan, the next few
         # fill the allocator's pools and bring host and device clocks up (the first ~30 operator calls of a process run
         # slower, see tests/tools/bench_configs.py)
+        import gc
+        gc.collect()   # here, with the device idle anyway, not between warm-up and timing (see timed())
         for _ in range(SETUP_STEPS):
             self.step()
         torch.cuda.synchronize(dev)
@@ -260,16 +262,18 @@ def main():
         """`warmup` untimed steps, then exactly `steps` timed ones between barriers (barrier = device synchronise + process
         barrier).  The collector is held off for the timed steps: a collection pass in a 13 ms region shows up as +10 %."""
         import gc
-        late = os.environ.get("DFGNN_BENCH_GC_LATE") == "1"   # (A/B switch: the collection pass between warm-up and timing)
-        if not late:
-            # the collection pass goes BEFORE the warm-up steps: it takes tens of milliseconds of host time, and with the device
-            # idle that long the first timed steps run at ramping clocks (seen as +3..4 % on a 20-step region)
+        mode = os.environ.get("DFGNN_BENCH_GC", "setup")   # (A/B switch: where the collection pass goes)
+        if mode == "early":
             gc.collect()
+        if mode != "late":
+            # the collection pass is NOT between warm-up and timing: it takes tens of milliseconds of host time, and with the
+            # device idle that long the first timed steps run at ramping clocks (seen as +2..4 % on a 20-step region).  It runs
+            # when the workload is set up, ahead of its set-up steps (Workload.__init__)
             gc.disable()
         for _ in range(warmup):
             w.step()
         barrier()
-        if late:
+        if mode == "late":
             gc.collect()
             gc.disable()
         try:
