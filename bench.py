@@ -106,9 +106,18 @@ def algorithmic_bytes_ranked(m, nnz, h, f):
     }
 
 
-def ev_us(fn, reps=10, warm=3):
-    """Mean device time of fn() in microseconds (events on torch's current stream = the launch stream)."""
+def ev_us(fn, reps=10, warm=3, steady_ms=8.0):
+    """Mean device time of fn() in microseconds (events on torch's current stream = the launch stream).  After the `warm`
+    calls fn() is repeated until about `steady_ms` of device work lie behind the measurement: a device that idled through the
+    host work before this call runs its first milliseconds at ramping clocks (the same effect as in timed(), main())."""
+    a0, b0 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a0.record()
     for _ in range(warm):
+        fn()
+    b0.record()
+    torch.cuda.synchronize()
+    per_call_ms = max(a0.elapsed_time(b0) / max(warm, 1), 1e-3)
+    for _ in range(min(400, int(steady_ms / per_call_ms))):
         fn()
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
     for a, b in evs:
@@ -119,8 +128,15 @@ def ev_us(fn, reps=10, warm=3):
     return float(np.mean([a.elapsed_time(b) for a, b in evs])) * 1e3
 
 
-def wall_ms(fn, reps=10, warm=3):
+def wall_ms(fn, reps=10, warm=3, steady_ms=8.0):
+    """Wall time per fn() call in ms; like ev_us, about `steady_ms` of device work lie right behind the timed calls."""
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
     for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    per_call_ms = max((time.perf_counter() - t0) * 1e3 / max(warm, 1), 1e-3)
+    for _ in range(min(400, int(steady_ms / per_call_ms))):
         fn()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
