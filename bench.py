@@ -576,10 +576,12 @@ def main():
         c_args = [t.numpy() for t in (c_rp, c_ci, c_ar, c_ac)] + [0.2, c_x.numpy()]
         for _ in range(3):
             oracle.gat_forward(*c_args, acc="f32")
-        t0 = time.perf_counter()
-        for _ in range(20):
+        c_times = []
+        for _ in range(20):   # median of the calls: a 55 us call on 128 OpenMP threads is at the mercy of the host's other tenants
+            t0 = time.perf_counter()
             oracle.gat_forward(*c_args, acc="f32")
-        c_dt = (time.perf_counter() - t0) / 20
+            c_times.append(time.perf_counter() - t0)
+        c_dt = sorted(c_times)[len(c_times) // 2]
         cpu["c1_gat_cora_f64"] = {"workload": "GAT conv 'csr' on a cora-like graph, dim=64 (BASELINE.json configs[0]), CPU port",
                                   "edges": gc.num_edges(), "ms": round(c_dt * 1e3, 4),
                                   "edges_per_s": gc.num_edges() / c_dt, "cores": oracle.num_threads()}
