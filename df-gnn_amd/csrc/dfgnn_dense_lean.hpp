@@ -33,7 +33,7 @@ __global__ __launch_bounds__(kLeanThreads, 2) void gt_dense_fwd_lean_kernel(Csr 
                                                                            float *__restrict__ stat_max = nullptr,
                                                                            float *__restrict__ stat_sum = nullptr) {
   static_assert(F == 64 || F == 128, "lean forward: whole 64-column halves only");
-  static_assert(!(STATS && WRITE_ATTN), "the statistics-saving forward writes no attention values");
+  // STATS && WRITE_ATTN: the rank-ordered training forward (see dense_fwd_body)
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int FW = 64, NH = F / FW, NP = 128, NT = NP / 16, NS = 2, PRE = 16;
   using D = DenseCfg<FW>;
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(kLeanThreads, 2) void gt_dense_fwd_lean_kernel(Csr 
 
   // ---- prologue: everything that is needed first is requested first ------------------------------------------------
   int rp_mine = 0;
-  if constexpr (!STATS) {
+  if constexpr (!STATS || WRITE_ATTN) {
     const int tid = opaque_tid();
     if (tid <= n) rp_mine = g.row_ptr[n0 + tid];
   }
@@ -151,6 +151,10 @@ __global__ __launch_bounds__(kLeanThreads, 2) void gt_dense_fwd_lean_kernel(Csr 
           g.mask + (size_t)(n0 + min((wave + kLeanWaves * s) * 16 + L.mi, n - 1)) * kPlanMaskWords);
       mwords[s][0] = w.x; mwords[s][1] = w.y; mwords[s][2] = w.z; mwords[s][3] = w.w;
     }
+  }
+  if constexpr (STATS && WRITE_ATTN) {  // (read long after the image barriers below)
+    const int tid = opaque_tid();
+    if (tid <= n) rp[tid] = rp_mine - e0;
   }
   if constexpr (!STATS) {
     const int tid = opaque_tid();
@@ -262,7 +266,7 @@ __global__ __launch_bounds__(kLeanThreads, 2) void gt_dense_fwd_lean_kernel(Csr 
       sum = xor16_32_sum(sum);
       inv[s] = (sum != 0.f) ? 1.f / sum : 0.f;
       if constexpr (STATS) {
-        if (i < n && L.mq == 0) {
+        if (stat_max && i < n && L.mq == 0) {
           stat_max[(size_t)(n0 + i) * g.h + head] = (mx == -INFINITY) ? -1e38f : mx;
           stat_sum[(size_t)(n0 + i) * g.h + head] = sum;
         }
@@ -272,10 +276,22 @@ __global__ __launch_bounds__(kLeanThreads, 2) void gt_dense_fwd_lean_kernel(Csr 
           float *lrow = pstage + rp[i];
           float *grow = attn_edge + (size_t)head * g.nnz + e0 + rp[i];
           auto scatter = [&](float *row) {
+            unsigned before = 0;  // (STATS) set bits of the bitmap words in front of the current one
 #pragma unroll
             for (int jt = 0; jt < NT; ++jt) {
               if (jt < ntile) {
-                const unsigned w = *reinterpret_cast<const unsigned *>(mrow + 16 * jt);
+                unsigned w;
+                if constexpr (!STATS) {
+                  w = *reinterpret_cast<const unsigned *>(mrow + 16 * jt);
+                } else {  // the ranks of this lane's 4 pairs among the set bits of its row's bitmap (see dense_fwd_body)
+                  const unsigned word = mwords[s][STATS ? jt / 2 : 0], low = 16u * (jt & 1) + 4u * L.mq;
+                  const unsigned b4 = (word >> low) & 0xFu;
+                  const unsigned r0 = before + __popc(word & ((1u << low) - 1u));
+                  const unsigned r1 = r0 + (b4 & 1u), r2 = r1 + ((b4 >> 1) & 1u), r3 = r2 + ((b4 >> 2) & 1u);
+                  if (jt & 1) before += __popc(word);
+                  w = ((b4 & 1u) ? r0 : 0xFFu) | (((b4 & 2u) ? r1 : 0xFFu) << 8) | (((b4 & 4u) ? r2 : 0xFFu) << 16) |
+                      (((b4 & 8u) ? r3 : 0xFFu) << 24);
+                }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                   const unsigned slot = (w >> (8 * r)) & 0xFFu;

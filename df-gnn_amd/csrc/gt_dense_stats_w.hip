@@ -11,6 +11,7 @@
 // One instance per shape: the range classes of the unit-value pair (<= 128, 129-160, > 160 nodes) per (range, head) --
 // the all-heads-in-one-workgroup bodies are not instantiated for weights.  Inference with weights runs the forward
 // without statistics (null pointers).
+#include <cstdlib>
 #include <type_traits>
 
 #include "dfgnn_dense.hpp"
@@ -19,6 +20,7 @@
 #define DFGNN_RING160 2
 #endif
 #include "dfgnn_dense_wide.hpp"
+#include "dfgnn_dense_lean.hpp"
 #include "dfgnn_dense_heads.hpp"
 #include "dfgnn_dense_fwd.hpp"
 #include "dfgnn_dense_bwd.hpp"
@@ -168,14 +170,29 @@ int launch_gt_dense_bwd_stats_w(const Csr &g, const Plan &p, const float *Q, con
   });
 }
 
+static bool ranked_lean_enabled() {  // DFGNN_LEAN=0 (diagnostic switch, read once): every dense range on the 512-thread forward
+  static const bool on = [] { const char *e = getenv("DFGNN_LEAN"); return !e || atoi(e) != 0; }();
+  return on;
+}
+
 int launch_gt_dense_fwd_ranked(const Csr &g_in, const Plan &p, const float *Q, const float *K, const float *V,
                                float *attn_ranked, float *out, hipStream_t s) {
   if (p.num_dense == 0) return 0;
   Csr g = g_in;
   g.mask = p.mask();
   const dim3 grid(p.num_dense, 1);
+  // a one-head batch without ranges of more than 128 nodes: the 256-thread forward, two workgroups per CU
+  const bool lean = (g.f == 64 || g.f == 128) && g.h == 1 && p.num_dense_wide == 0 && ranked_lean_enabled();
   return dispatch_dense_w(g.f, [&](auto fc) {
     constexpr int F = decltype(fc)::value;
+    if constexpr (F == 64 || F == 128) {
+      if (lean) {
+        if (int rc = set_max_lds_cached(gt_dense_fwd_lean_kernel<F, true, true>)) return rc;
+        gt_dense_fwd_lean_kernel<F, true, true><<<grid, kLeanThreads, kLeanLdsBytes, s>>>(g, p.fit(), Q, K, V, attn_ranked, out, nullptr,
+                                                                                         nullptr);
+        return launch_status();
+      }
+    }
     if (g.h == 1) {
       if (int rc = set_max_lds_cached(gt_dense_fwd_ranked_kernel<F>)) return rc;
       gt_dense_fwd_ranked_kernel<F><<<grid, kDenseThreads, kLdsBytes, s>>>(g, p.fit(), Q, K, V, attn_ranked, out, kLdsBytes);

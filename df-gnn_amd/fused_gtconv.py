@@ -207,16 +207,13 @@ def gt_ranked_pair_applies(row_ptr, col_ind, val, Q):
 
 
 def gt_ranked_pair_chosen(row_ptr, col_ind, val, Q):
-    """gt_ranked_pair_applies under the measured policy: at one head, for batches that hold a range of more than 128
-    nodes (C3: forward 97 -> 84 us).  A one-head batch without any has the CSR-ordered pair's 256-thread forward, two
-    workgroups per CU, which is the faster one there (107-node graphs: 74 against 78 us); RANKED_HEADS widens the head
-    counts (DFGNN_RANKED_HEADS=1,2,4)."""
+    """gt_ranked_pair_applies under the measured policy: at one head (C3: forward 95 -> 85 us; batches without a range of
+    more than 128 nodes take the 256-thread form of the same forward, two workgroups per CU).  With several heads the
+    rank-ordered forward times like the CSR-ordered one and the statistics pair is the faster choice; RANKED_HEADS widens
+    the head counts for A/B runs (DFGNN_RANKED_HEADS=1,2,4)."""
     if Q.dim() != 3 or Q.size(1) not in RANKED_HEADS:
         return None
-    plan = gt_ranked_pair_applies(row_ptr, col_ind, val, Q)
-    if plan is not None and (Q.size(1) > 1 or plan.num_dense_wide > 0 or Q.size(-1) not in (64, 128)):
-        return plan
-    return None
+    return gt_ranked_pair_applies(row_ptr, col_ind, val, Q)
 
 
 def gt_hyper_forward_ranked(row_ptr, col_ind, Q, K, V, plan=None):

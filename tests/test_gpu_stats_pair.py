@@ -180,6 +180,22 @@ def test_ranked_pair_equals_the_attn_edge_pair(oracle_mod, f):
     assert torch.equal(o.detach(), out) and torch.equal(Qg.grad, dQ) and torch.equal(Kg.grad, dK) and torch.equal(Vg.grad, dV)
     # edge values: not this pair's (they go to the statistics pair)
     assert gt.gt_ranked_pair_applies(row_ptr, col_ind, torch.rand_like(val) + 0.5, Q) is None
+    # a batch without ranges of more than 128 nodes: the 256-thread form of the forward (widths 64 and 128)
+    gs = S.pattern_like(batch_size=24, seed=3 + f, mean_nodes=90.0, std_nodes=20.0, lo=20, hi=128, mean_deg=30.0).to(DEV)
+    A, rows, row_ptr, col_ind, val, col_ptr, row_ind, val_idx, smem = preprocess_Hyper_fw_bw(gs)
+    Q, K, V = S.gt_features(gs.num_nodes(), 1, f, seed=8, device=DEV)
+    dO = torch.randn(gs.num_nodes(), 1, f, generator=torch.Generator().manual_seed(5)).to(DEV)
+    plan = gt.gt_ranked_pair_chosen(row_ptr, col_ind, val, Q)
+    assert plan is not None and plan.num_dense_wide == 0
+    out, attn_r = gt.gt_hyper_forward_ranked(row_ptr, col_ind, Q, K, V, plan=plan)
+    dQ, dK, dV = gt.gt_backward_ranked(row_ptr, col_ind, Q, K, V, attn_r, dO, plan=plan)
+    args = (row_ptr, col_ind, rows, val, col_ptr, row_ind, val_idx, smem, Q, K, V)
+    out_a, attn = gt.gt_hyper_forward(*args)
+    dQ_a, dK_a, dV_a = gt.gt_backward(*args, attn, dO)
+    assert torch.equal(out, out_a) and torch.equal(dQ, dQ_a) and torch.equal(dK, dK_a) and torch.equal(dV, dV_a)
+    rp, ci = row_ptr.cpu().numpy(), col_ind.cpu().numpy().astype(np.int64)
+    order = np.lexsort((ci, np.repeat(np.arange(gs.num_nodes()), np.diff(rp))))
+    assert np.array_equal(attn_r.cpu().numpy().reshape(-1), attn.cpu().numpy().reshape(-1)[order])
 
 
 @pytest.mark.parametrize("h,f", [(2, 64), (4, 32), (8, 16), (3, 32), (2, 128), (2, 8)])
