@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Profiling helper: run one hot-path entry point a few times on the C3 workload (for rocprofv3).
-usage: python3 tools/run_kernel.py [fwd|bwd|fwd_stats|bwd_stats|pairs|fwd_infer|gat|gat_train|gat_train_drop|c4] [iters] [batch_size]"""
+usage: python3 tools/run_kernel.py [fwd|bwd|fwd_stats|bwd_stats|pairs|step|fwd_infer|gat|gat_train|gat_train_drop|c4] [iters] [batch_size]"""
 import os
 import sys
 
@@ -51,6 +51,15 @@ if what.startswith("gat_train"):
     for _ in range(iters):
         out, emax, esum, mask = gat.gat_forward(ar, ac, row_ptr, col_ind, 0.2, X, drop)
         gat.gat_backward(0.2, drop, row_ptr, col_ind, col_ptr, row_ind, val_idx, emax, esum, mask, X, ar, ac, dO)
+    torch.cuda.synchronize()
+    print("done", what, iters, m, g.num_edges())
+    sys.exit(0)
+if what == "step":  # the headline step itself (autograd function: whatever pair it chooses), nothing else on the device
+    from DFGNN.operators.fused_gtconv import GTConvFuse_hyper
+    Qg, Kg, Vg = (t.requires_grad_(True) for t in (Q, K, V))
+    for _ in range(iters):
+        o = GTConvFuse_hyper(rows, row_ptr, col_ind, val, col_ptr, row_ind, val_idx, smem, Qg, Kg, Vg)
+        torch.autograd.grad(o, (Qg, Kg, Vg), dO)
     torch.cuda.synchronize()
     print("done", what, iters, m, g.num_edges())
     sys.exit(0)
