@@ -125,6 +125,8 @@ int launch_gt_dense_fwd(const Csr &g, const Plan &p, const float *Q, const float
 int launch_gt_dense_bwd(const Csr &g, const Plan &p, const float *Q, const float *K, const float *V,
                         const float *attn_edge, const float *grad_out, float *dQ, float *dK, float *dV,
                         hipStream_t s, bool ranked = false);
+// ranges a backward keeps in plan position (the largest); it takes the others in reverse plan order (gt_dense.hip says why)
+int bwd_reverse_keep(int num_dense);
 // the statistics-saving training pair (gt_dense_stats.hip): no attn_edge, row statistics [m, h] instead
 int launch_gt_dense_fwd_stats(const Csr &g, const Plan &p, const float *Q, const float *K, const float *V, float *out,
                               float *stat_max, float *stat_sum, hipStream_t s);

@@ -86,9 +86,11 @@ template <int F>
 __global__ __launch_bounds__(kDenseThreads) void gt_dense_bwd_stats_kernel(
     Csr g, const int *__restrict__ fit, const float *__restrict__ Q, const float *__restrict__ K,
     const float *__restrict__ V, const float *__restrict__ stat_max, const float *__restrict__ stat_sum,
-    const float *__restrict__ dO, float *__restrict__ dQ, float *__restrict__ dK, float *__restrict__ dV, int heads2) {
+    const float *__restrict__ dO, float *__restrict__ dQ, float *__restrict__ dK, float *__restrict__ dV, int heads2, int keep) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int range = blockIdx.x, head = blockIdx.y;
+  int range = blockIdx.x;
+  const int head = blockIdx.y;
+  if (keep >= 0 && range >= keep) range = (int)gridDim.x - 1 - (range - keep);  // (launch_gt_dense_bwd, gt_dense.hip)
   const int n0 = fit[2 * range], n1 = fit[2 * range + 1] & kPlanRangeMask;
   const int n = n1 - n0;
   if constexpr (F == 16 || F == 32 || F == 64) {
@@ -174,7 +176,7 @@ int launch_gt_dense_bwd_stats(const Csr &g_in, const Plan &p, const float *Q, co
     constexpr int F = decltype(fc)::value;
     if (int rc = set_max_lds_cached(gt_dense_bwd_stats_kernel<F>)) return rc;
     gt_dense_bwd_stats_kernel<F><<<grid, kDenseThreads, kLdsBytes, s>>>(g, p.fit(), Q, K, V, stat_max, stat_sum, grad_out, dQ, dK,
-                                                                        dV, heads2);
+                                                                        dV, heads2, g.h == 1 ? bwd_reverse_keep(p.num_dense) : -1);  // (several heads: measured, no gain)
     return launch_status();
   });
 }

@@ -3,8 +3,9 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/step_trace; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-for v in ranked csr stats; do
-  case $v in ranked) export DFGNN_RANKED=1 DFGNN_STATS=auto;; csr) export DFGNN_RANKED=0 DFGNN_STATS=auto;; stats) export DFGNN_RANKED=1 DFGNN_STATS=1;; esac
+for v in ${STEP_TRACE_VARIANTS:-ranked csr stats}; do
+  unset DFGNN_BWD_REVERSE
+  case $v in ranked) export DFGNN_RANKED=1 DFGNN_STATS=auto;; csr) export DFGNN_RANKED=0 DFGNN_STATS=auto;; stats) export DFGNN_RANKED=1 DFGNN_STATS=1;; rev*) export DFGNN_RANKED=1 DFGNN_STATS=auto DFGNN_BWD_REVERSE=${v#rev};; esac
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/p_$v -o t -- python3 $R/tools/run_kernel.py step 200 > $O/$v.log 2>&1
   find $O/p_$v -name "*kernel_stats.csv" -exec cp {} $O/${v}_kernel_stats.csv \;
   find $O/p_$v -name "*kernel_trace.csv" -exec cp {} $O/${v}_kernel_trace.csv \;
@@ -13,7 +14,7 @@ done
 python3 - <<'PY'
 import csv, os, numpy as np
 O = os.path.join(os.environ.get("GRAFT_REPO_ROOT", "/root/repo"), "gpurun_out/step_trace")
-for v in ("ranked", "csr", "stats"):
+for v in os.environ.get("STEP_TRACE_VARIANTS", "ranked csr stats").split():
     rows = [r for r in csv.DictReader(open(f"{O}/{v}_kernel_trace.csv")) if "gt_dense" in r["Kernel_Name"]]
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     rows = rows[100:]                     # steady part
