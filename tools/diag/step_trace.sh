@@ -4,8 +4,8 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/step_trace; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 for v in ${STEP_TRACE_VARIANTS:-ranked csr stats}; do
-  unset DFGNN_BWD_REVERSE
-  case $v in ranked) export DFGNN_RANKED=1 DFGNN_STATS=auto;; csr) export DFGNN_RANKED=0 DFGNN_STATS=auto;; stats) export DFGNN_RANKED=1 DFGNN_STATS=1;; rev*) export DFGNN_RANKED=1 DFGNN_STATS=auto DFGNN_BWD_REVERSE=${v#rev};; esac
+  unset DFGNN_BWD_REVERSE DFGNN_LIB
+  case $v in ranked) export DFGNN_RANKED=1 DFGNN_STATS=auto;; csr) export DFGNN_RANKED=0 DFGNN_STATS=auto;; stats) export DFGNN_RANKED=1 DFGNN_STATS=1;; rev*) export DFGNN_RANKED=1 DFGNN_STATS=auto DFGNN_BWD_REVERSE=${v#rev};; lib_*) export DFGNN_RANKED=1 DFGNN_STATS=auto DFGNN_LIB=libdfgnn_${v#lib_}.so;; esac
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/p_$v -o t -- python3 $R/tools/run_kernel.py step 200 > $O/$v.log 2>&1
   find $O/p_$v -name "*kernel_stats.csv" -exec cp {} $O/${v}_kernel_stats.csv \;
   find $O/p_$v -name "*kernel_trace.csv" -exec cp {} $O/${v}_kernel_trace.csv \;
