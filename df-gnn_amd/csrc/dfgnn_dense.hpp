@@ -125,6 +125,29 @@ __device__ __forceinline__ void st32_f4(float *base, unsigned idx, const float4 
   DFGNN_LDS_AT(reinterpret_cast<char *>(base) + (size_t)(idx * 4u), 16u);
   *reinterpret_cast<float4 *>(reinterpret_cast<char *>(base) + (size_t)(idx * 4u)) = v;
 }
+// Loads of data these kernels read ONCE and nothing of the pair reads again (dO, the attention values and edge coordinates
+// of a backward): non-temporal, for the same reason as the stores below.  -DDFGNN_NT_LOADS=0: plain loads (A/B).
+#ifndef DFGNN_NT_LOADS
+#define DFGNN_NT_LOADS 1
+#endif
+template <class T>
+__device__ __forceinline__ T ld32_once(const T *base, unsigned idx) {
+  const T *p = reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + (size_t)(idx * (unsigned)sizeof(T)));
+#if DFGNN_NT_LOADS
+  return __builtin_nontemporal_load(p);
+#else
+  return *p;
+#endif
+}
+__device__ __forceinline__ float4 ld32_f4_once(const float *base, unsigned idx) {
+#if DFGNN_NT_LOADS
+  typedef float f4v __attribute__((ext_vector_type(4)));
+  const f4v x = __builtin_nontemporal_load(reinterpret_cast<const f4v *>(reinterpret_cast<const char *>(base) + (size_t)(idx * 4u)));
+  return make_float4(x[0], x[1], x[2], x[3]);
+#else
+  return ld32_f4(base, idx);
+#endif
+}
 // The same for an OUTPUT row in global memory (out, dQ, dK, dV: written once, not read again by these kernels), as a
 // NON-TEMPORAL store: the outputs then do not push the inputs out of L2 / the Infinity Cache.  A step moves 270 MB (forward)
 // and 490 MB (backward) past a 256 MB cache; with 62 / 185 MB of that streamed, the backward finds more of what the forward
@@ -174,9 +197,10 @@ struct DenseStageRegs {
 // when the image is stored): a load under a branch is waited for right behind the branch, one round trip per piece.
 // fr < F (a narrower matrix run on the F-wide kernels, e.g. f = 16 heads on the 32-wide instance): the pieces past fr are
 // read from the row's first piece instead (a valid address) and zeroed with the padding rows.
+// once (a literal at every call site, so that it folds): the matrix is read once and not again -- non-temporal loads.
 template <int F, int ROWS>
 __device__ __forceinline__ void dense_stage_load(DenseStageRegs<F, ROWS> &r, const float *__restrict__ src, size_t hf,
-                                                 int row0, int row_end, int fr = F) {
+                                                 int row0, int row_end, int fr = F, bool once = false) {
   constexpr int C8 = F / 8;
   const int tid = opaque_tid();
   r.row0 = row0;
@@ -186,8 +210,8 @@ __device__ __forceinline__ void dense_stage_load(DenseStageRegs<F, ROWS> &r, con
     const int idx = tid + k * kDenseThreads;
     const int row = min(idx / C8, ROWS - 1), c8 = idx % C8;
     const unsigned off = (unsigned)min(row0 + row, row_end - 1) * (unsigned)hf + ((fr >= F || 8 * c8 < fr) ? 8u * c8 : 0u);
-    r.a[k] = ld32_f4(src, off);
-    r.b[k] = ld32_f4(src, off + 4);
+    r.a[k] = once ? ld32_f4_once(src, off) : ld32_f4(src, off);
+    r.b[k] = once ? ld32_f4_once(src, off + 4) : ld32_f4(src, off + 4);
   }
 }
 

@@ -89,13 +89,13 @@ __device__ __forceinline__ void dense_bwd_body(float *lds, const Csr &g, int n0,
   DenseStageRegs<F, CW> st;
   const float *next_src = nullptr;
   int next_row0 = 0, next_end = 0;
-  auto image_prefetch = [&](const float *src, int row0, int row_end) {
+  auto image_prefetch = [&](const float *src, int row0, int row_end, bool once = false) {  // once: see dense_stage_load
     if (NBLK > 1) {
       next_src = src;
       next_row0 = row0;
       next_end = row_end;
     } else {
-      dense_stage_load<F, CW>(st, src, hf, row0, row_end, fr);
+      dense_stage_load<F, CW>(st, src, hf, row0, row_end, fr, once);
     }
   };
   // An image goes to LDS in two steps around a barrier the phase structure has anyway: image_post() (with two column
@@ -122,8 +122,8 @@ __device__ __forceinline__ void dense_bwd_body(float *lds, const Csr &g, int n0,
       // clamped: plain loads (a row block without edges -- rows with in-edges only -- reads the last edge, unused)
       const unsigned e = (unsigned)min(tid + k * kDenseThreads, max(eb - ea, 1) - 1);
       const int ea0 = min(ea, g.nnz - 1);
-      pc[k] = ld32(g.coords + ea0, e);
-      if constexpr (!GAT) pa[k] = ld32(attn_h + ea0, e);
+      pc[k] = ld32_once(g.coords + ea0, e);
+      if constexpr (!GAT) pa[k] = ld32_once(attn_h + ea0, e);
       else pa[k] = ga.drop.mask ? ga.drop.mask[((size_t)ea0 + e) * g.h + head] : 1.f;
     }
   };
@@ -174,8 +174,8 @@ __device__ __forceinline__ void dense_bwd_body(float *lds, const Csr &g, int n0,
 #pragma unroll
       for (int k = 0; k < B; ++k) {
         const unsigned e = (unsigned)min(base + tid + k * kDenseThreads, eb - ea - 1);  // (eb > ea inside this loop)
-        bc[k] = ld32(g.coords + ea, e);
-        if constexpr (!GAT) ba[k] = ld32(attn_h + ea, e);
+        bc[k] = ld32_once(g.coords + ea, e);
+        if constexpr (!GAT) ba[k] = ld32_once(attn_h + ea, e);
         else ba[k] = ga.drop.mask ? ga.drop.mask[((size_t)ea + e) * g.h + head] : 1.f;
       }
 #pragma unroll
@@ -301,7 +301,7 @@ __device__ __forceinline__ void dense_bwd_body(float *lds, const Csr &g, int n0,
     image_prefetch(Kb, 0, n);  // the first image: K rows of column block 0
   } else {
     edges_prefetch(ea, eb);
-    image_prefetch(dOb, 0, min(n, RB));
+    image_prefetch(dOb, 0, min(n, RB), !RECOMP && !GAT);  // (the attn_edge form reads dO once)
     tile_open(ea, eb);
   }
   float gcol = 0.f;  // GAT: grad_attn_col of column opaque_tid(), accumulated over the row blocks

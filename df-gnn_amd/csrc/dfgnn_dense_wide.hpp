@@ -76,8 +76,8 @@ __device__ __forceinline__ void dense_bwd_wide_body(float *lds, const Csr &g, in
 #pragma unroll
     for (int k = 0; k < PRE; ++k) {
       const unsigned e = (unsigned)min(tid + k * kDenseThreads, max(ne, 1) - 1);
-      pc[k] = ld32(g.coords + e0, e);
-      pa[k] = ld32(attn_h, e);
+      pc[k] = ld32_once(g.coords + e0, e);
+      pa[k] = ld32_once(attn_h, e);
     }
   }
   DenseStageRegs<FW, NP> st[R];  // image q travels in st[q % R]
@@ -90,7 +90,9 @@ __device__ __forceinline__ void dense_bwd_wide_body(float *lds, const Csr &g, in
     return base + h * FW;
   };
   auto image_fetch = [&](int q) {
-    if (q < NQ) dense_stage_load<FW, NP>(st[q % R], image_src(q), hf, 0, n, fr);
+    // (dO -- the even images of the first 2 NH behind the K images of RECOMP -- is read once by the attn_edge form)
+    const bool once = !RECOMP && q >= QB && q - QB < 2 * NH && ((q - QB) & 1) == 0;
+    if (q < NQ) dense_stage_load<FW, NP>(st[q % R], image_src(q), hf, 0, n, fr, once);
   };
   auto image_post = [&](int q) { wg_max_post(smax, dense_stage_absmax<FW, NP>(st[q % R])); };
   auto image_store = [&](int q) {  // ... and the register set is refilled with the image R phases on
@@ -238,8 +240,8 @@ __device__ __forceinline__ void dense_bwd_wide_body(float *lds, const Csr &g, in
 #pragma unroll
       for (int k = 0; k < B; ++k) {
         const unsigned e = (unsigned)min(base + tid + k * kDenseThreads, ne - 1);
-        bc[k] = ld32(g.coords + e0, e);
-        ba[k] = ld32(attn_h, e);
+        bc[k] = ld32_once(g.coords + e0, e);
+        ba[k] = ld32_once(attn_h, e);
       }
 #pragma unroll
       for (int k = 0; k < B; ++k)
